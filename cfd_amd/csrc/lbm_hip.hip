@@ -1,0 +1,1074 @@
+// lbm_hip.hip -- MI355X (gfx950) D3Q19 lattice-Boltzmann hot path behind include/lbm_abi.h.
+//
+// Replaces Engine/src/Physics/lbm_solver.cu of the reference (kernels :37-64, :242-402,
+// :498-513, :612-656 and the host methods around them).  Written for CDNA4 from scratch:
+//   * populations: SoA fp32, 19 planes; a plane is (D+2) z-layers (one ghost layer each side for
+//     the slab halo) of H rows of Wp floats, Wp = W rounded up to 32 floats (128-byte rows);
+//     consecutive planes are separated by a skew so the 19+19 streams do not alias in HBM;
+//   * solid mask: bit-packed, one 64-bit word per 64 cells along x (= one wave64 row segment),
+//     with the same ghost layers;
+//   * one wave64 owns 64 consecutive x cells of one (y,z) row.  A byte per such tile, rebuilt
+//     when the mask changes, says whether the tile can take the branch-free interior path
+//     (no wall row, no solid cell in the 3x3x66 neighbourhood) or needs the full boundary
+//     chain of the reference (lbm_solver.cu:283-318), evaluated per lane in logical
+//     (plane,x,y,z) coordinates;
+//   * pull-scheme A/B: gather 19 loads -> moments -> collision -> 19 non-temporal stores,
+//     152 algorithmic bytes per cell update; rho/u/curl are materialised on demand from the
+//     previous buffer with the same gather, so they are bit-identical to per-step writes;
+//   * arithmetic is the reference's fp32 operation order with contraction off (d3q19.h), so
+//     results match the CPU oracle bit for bit.
+// HBM-bound integer/float streaming work: no MFMA, no LDS staging.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lbm_abi.h"
+#include "d3q19.h"
+#include "voxelizer.h"
+
+using namespace d3q19;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// geometry shared by host and device
+// ------------------------------------------------------------------------------------------
+struct Geo {
+    int W, H, D;        // owned extent of this context
+    int Dg, z0;         // global depth, global z of owned layer 0
+    int slab;           // 1: one z-slab of a taller domain (ghost layers are fed by the halo exchange)
+    int Wp;             // floats per row (multiple of 32)
+    int Wm;             // 64-bit mask words per row
+    int Wt;             // 64-cell tiles per row (= Wm)
+    long long layer;    // floats per z layer (H*Wp)
+    long long plane;    // floats between consecutive population planes
+};
+
+struct Params {
+    float U, omega_shear, omega_bulk;
+};
+
+// device address of cell (x, y, zl) inside a plane; zl = local layer index incl. ghost (owned: 1..D)
+__device__ __forceinline__ long long cell_off(const Geo& g, int x, int y, int zl) {
+    return (long long)zl * g.layer + (long long)y * g.Wp + x;
+}
+
+__device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long* __restrict__ mask,
+                                         int x, int y, int zl) {
+    const unsigned long long w = mask[((long long)zl * g.H + y) * g.Wm + (x >> 6)];
+    return (w >> (x & 63)) & 1ull;
+}
+
+// Which branch of the reference chain (lbm_solver.cu:283-318) feeds direction K of the fluid cell
+// (x, y, zl).  Single source of truth for the step kernel, the moment kernel and
+// lbm_read_classification.
+template <int PRESET, int K>
+__device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                 int x, int y, int zl) {
+    constexpr int cx = CX[K], cy = CY[K], cz = CZ[K];
+    const int nx = x - cx, ny = y - cy;
+    const int nzg = (zl - 1) + g.z0 - cz;
+    if (PRESET == LBM_PRESET_CAVITY) {
+        if (cy == -1 && ny >= g.H) return SRC_LID_BB;
+        if ((cx == 1 && nx < 0) || (cx == -1 && nx >= g.W) || (cy == 1 && ny < 0) ||
+            (cz != 0 && (nzg < 0 || nzg >= g.Dg)))
+            return SRC_WALL_BB;
+    } else {
+        if (cx == 1 && nx < 0) return SRC_INLET;
+        if (cx == -1 && nx >= g.W) return SRC_OUTLET;
+        if (cy == 1 && ny < 0) return SRC_FLOOR_BB;
+        if (cy == -1 && ny >= g.H) return SRC_CEIL_RFY;
+        if (cz != 0 && (nzg < 0 || nzg >= g.Dg)) return SRC_SIDE_RFZ;
+    }
+    if (K == 0) return SRC_PULL;
+    return solid_at(g, mask, nx, ny, zl - cz) ? SRC_SOLID_BB : SRC_PULL;
+}
+
+// Outlet branch (lbm_solver.cu:292-296): the reference indexes f_in[k*n + nz*W*H + ny*W + (W-1)]
+// without range-checking ny/nz, so a row off the y end carries into the next z layer and a layer
+// off the z end carries into the neighbouring population plane (quirk Q2).  Our planes are padded,
+// so the carry is applied in logical coordinates.
+template <int K>
+__device__ __forceinline__ float outlet_read(const Geo& g, const float* __restrict__ fin, int y, int zl) {
+    int pl = K;
+    int ny = y - CY[K];
+    int nzg = (zl - 1) + g.z0 - CZ[K];
+    if (ny < 0) { ny += g.H; nzg -= 1; }
+    else if (ny >= g.H) { ny -= g.H; nzg += 1; }
+    // An undecomposed domain holds the wrapped layer itself; a slab finds it in its ghost layer,
+    // where the ring halo exchange put the neighbour's values (see k_halo_unpack).
+    if (nzg < 0) { pl -= 1; if (!g.slab) nzg += g.Dg; }
+    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nzg -= g.Dg; }
+    const int nzl = nzg - g.z0 + 1;
+    return fin[(long long)pl * g.plane + cell_off(g, g.W - 1, ny, nzl)];
+}
+
+// full boundary chain for one direction, per lane
+template <int PRESET, int K>
+__device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin,
+                                                const unsigned long long* __restrict__ mask,
+                                                int x, int y, int zl, long long own, float inlet_e, float U) {
+    const unsigned code = classify_dir<PRESET, K>(g, mask, x, y, zl);
+    if (code == SRC_INLET) return weight(K) * inlet_e;
+    if (code == SRC_OUTLET) return outlet_read<K>(g, fin, y, zl);
+    int pl = K;
+    long long off = own;
+    if (code == SRC_PULL) off = cell_off(g, x - CX[K], y - CY[K], zl - CZ[K]);
+    else if (code == SRC_CEIL_RFY) pl = RFY[K];
+    else if (code == SRC_SIDE_RFZ) pl = RFZ[K];
+    else pl = INV[K];  // floor / solid / wall / lid bounce-back
+    float v = fin[(long long)pl * g.plane + off];
+    if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
+    return v;
+}
+
+// interior tile: rows y-1..y+1 and layers z-1..z+1 exist, no solid cell within reach; only the
+// x ends of the row need care.
+template <int PRESET, int K>
+__device__ __forceinline__ float gather_fast(const Geo& g, const float* __restrict__ fin,
+                                             int x, int y, int zl, long long own, float inlet_e) {
+    constexpr int cx = CX[K];
+    const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
+                       (long long)(y - CY[K]) * g.Wp;
+    if (cx == 0) return row[x];
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
+        if (cx == 1) {
+            const float v = row[x - 1];  // x = 0 reads the pad/previous row: in bounds, discarded
+            return x == 0 ? weight(K) * inlet_e : v;
+        }
+        const int xs = x + 1 < g.W ? x + 1 : g.W - 1;  // outlet: copy from x = W-1 (ny, nz in range here)
+        return row[xs];
+    } else {
+        const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
+        if (wall) return fin[(long long)INV[K] * g.plane + own];
+        return row[x - cx];
+    }
+}
+
+template <int PRESET, int K>
+struct GatherAll {
+    static __device__ __forceinline__ void fast(const Geo& g, const float* __restrict__ fin, int x, int y,
+                                                int zl, long long own, float inlet_e, float* f) {
+        GatherAll<PRESET, K - 1>::fast(g, fin, x, y, zl, own, inlet_e, f);
+        f[K] = gather_fast<PRESET, K>(g, fin, x, y, zl, own, inlet_e);
+    }
+    static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin,
+                                                   const unsigned long long* __restrict__ mask, int x, int y,
+                                                   int zl, long long own, float inlet_e, float U, float* f) {
+        GatherAll<PRESET, K - 1>::general(g, fin, mask, x, y, zl, own, inlet_e, U, f);
+        f[K] = gather_general<PRESET, K>(g, fin, mask, x, y, zl, own, inlet_e, U);
+    }
+    static __device__ __forceinline__ void classify(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                    int x, int y, int zl, unsigned char* out) {
+        GatherAll<PRESET, K - 1>::classify(g, mask, x, y, zl, out);
+        out[K] = (unsigned char)classify_dir<PRESET, K>(g, mask, x, y, zl);
+    }
+};
+template <int PRESET>
+struct GatherAll<PRESET, -1> {
+    static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
+    static __device__ __forceinline__ void general(const Geo&, const float*, const unsigned long long*, int, int,
+                                                   int, long long, float, float, float*) {}
+    static __device__ __forceinline__ void classify(const Geo&, const unsigned long long*, int, int, int,
+                                                    unsigned char*) {}
+};
+
+// Tile -> (xs, y, z) mapping shared by the kernels that walk tiles: a 256-thread block is four
+// waves; `segsx` of them sit side by side in x, the rest stack in y.
+struct TileId {
+    int xs, y, lane;
+};
+__device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileId t;
+    t.lane = threadIdx.x & 63;
+    const int segsx = 1 << segsx_log2;
+    t.xs = blockIdx.x * segsx + (wave & (segsx - 1));
+    t.y = blockIdx.y * (4 >> segsx_log2) + (wave >> segsx_log2);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
+// MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
+// ------------------------------------------------------------------------------------------
+template <int PRESET, int MODE>
+__global__ __launch_bounds__(256) void k_stream_collide(
+    const float* __restrict__ fin, float* __restrict__ fout,
+    const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
+    float* __restrict__ rho_out, float4* __restrict__ u_out,
+    Geo g, Params p, int zl_begin, int segsx_log2) {
+    const TileId t = tile_of_wave(segsx_log2);
+    const int y = t.y;
+    const int zl = zl_begin + blockIdx.z;  // local layer incl. ghost offset (owned: 1..D)
+    if (t.xs >= g.Wt || y >= g.H) return;
+    const int x = t.xs * 64 + t.lane;
+    const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
+    if (x >= g.W) return;
+
+    const long long own = cell_off(g, x, y, zl);
+    const float inlet_e = inlet_bracket(p.U);
+    float f[Q];
+
+    if (flag == 0) {
+        GatherAll<PRESET, Q - 1>::fast(g, fin, x, y, zl, own, inlet_e, f);
+    } else {
+        if (solid_at(g, mask, x, y, zl)) {
+            // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
+            // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
+            if (MODE == 1) {
+                const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+                rho_out[ridx] = 0.0f;
+                u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
+        GatherAll<PRESET, Q - 1>::general(g, fin, mask, x, y, zl, own, inlet_e, p.U, f);
+    }
+
+    const Moments m = moments_of(f);
+    if (MODE == 1) {
+        const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+        rho_out[ridx] = m.rho;
+        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
+        return;
+    }
+    float o[Q];
+    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
+    float* dst = fout + own;
+#pragma unroll
+    for (int k = 0; k < Q; k++) __builtin_nontemporal_store(o[k], dst + (long long)k * g.plane);
+}
+
+// ------------------------------------------------------------------------------------------
+// set-up and read-back kernels
+// ------------------------------------------------------------------------------------------
+// k_init (lbm_solver.cu:37-64): equilibrium at rho = 1, u = 0 is f_k = w_k exactly.  Fills the
+// whole plane (ghost layers and row padding too) of both buffers.
+__global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, long long plane, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= count) return;
+    const float w = weight(k);
+    fa[(long long)k * plane + i] = w;
+    fb[(long long)k * plane + i] = w;
+}
+
+__global__ void k_fill_fields(float* __restrict__ rho, float4* __restrict__ u, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rho[i] = 1.0f;
+    u[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// dense u8 mask (reference wire format) -> bit-packed words of the owned layers
+__global__ void k_pack_mask(const unsigned char* __restrict__ dense, unsigned long long* __restrict__ mask, Geo g) {
+    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // word index over owned rows
+    const long long nwords = (long long)g.D * g.H * g.Wm;
+    if (wi >= nwords) return;
+    const long long row = wi / g.Wm;
+    const int xw = (int)(wi - row * g.Wm);
+    const unsigned char* src = dense + row * g.W + (long long)xw * 64;
+    const int cnt = min(64, g.W - xw * 64);
+    unsigned long long bits = 0;
+    for (int b = 0; b < cnt; b++) bits |= (unsigned long long)(src[b] > 0) << b;
+    mask[(long long)g.H * g.Wm + wi] = bits;  // skip the bottom ghost layer
+}
+
+__global__ void k_unpack_mask(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const unsigned long long w = mask[(long long)g.H * g.Wm + row * g.Wm + (x >> 6)];
+    dense[i] = ((w >> (x & 63)) & 1ull) ? 255 : 0;
+}
+
+// k_add_solid_rect (lbm_solver.cu:498-513) on the packed mask: one thread per word, no atomics.
+// Coordinates are global; this context owns global layers [z0, z0+D).
+__global__ void k_add_rect(unsigned long long* __restrict__ mask, Geo g, int rx, int ry, int rz, int rw, int rh, int rd) {
+    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nwords = (long long)(g.D + 2) * g.H * g.Wm;  // ghost layers included
+    if (wi >= nwords) return;
+    const long long row = wi / g.Wm;
+    const int xw = (int)(wi - row * g.Wm);
+    const int zl = (int)(row / g.H);
+    const int y = (int)(row - (long long)zl * g.H);
+    const int zg = zl - 1 + g.z0;
+    if (zg < 0 || zg >= g.Dg) return;
+    // 64-bit compares: rx + rw may exceed int range for hostile arguments
+    if (y < ry || (long long)y >= (long long)ry + rh || zg < rz || (long long)zg >= (long long)rz + rd) return;
+    long long lo = max((long long)rx, (long long)xw * 64);
+    long long hi = min(min((long long)rx + rw, (long long)g.W), (long long)xw * 64 + 64);
+    if (hi <= lo) return;
+    const int b0 = (int)(lo - (long long)xw * 64), cnt = (int)(hi - lo);
+    const unsigned long long bits = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << b0;
+    mask[wi] |= bits;
+}
+
+// per-tile path flag: 0 = interior fast path, 1 = full boundary chain
+template <int PRESET>
+__global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ flags, Geo g) {
+    const long long ti = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ntiles = (long long)g.D * g.H * g.Wt;
+    if (ti >= ntiles) return;
+    const long long row = ti / g.Wt;
+    const int xs = (int)(ti - row * g.Wt);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    const int zg = z + g.z0;
+    unsigned char fl = 0;
+    if (y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1) {
+        fl = 1;
+    } else {
+        unsigned long long any = 0;
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++) {
+                const unsigned long long* r = mask + ((long long)(z + 1 + dz) * g.H + (y + dy)) * g.Wm;
+                any |= r[xs];
+                if (xs > 0) any |= r[xs - 1] >> 63;
+                if (xs + 1 < g.Wm) any |= r[xs + 1] & 1ull;
+            }
+        fl = any != 0;
+    }
+    flags[ti] = fl;
+}
+
+// Solid cells keep their populations frozen; the reference re-copies them every step
+// (lbm_solver.cu:263-265), which only matters because the outlet branch may read a solid cell.
+// One copy cur -> other after the mask (or the populations) changed gives the same state.
+__global__ void k_sync_solid(const float* __restrict__ cur, float* __restrict__ other,
+                             const unsigned long long* __restrict__ mask, Geo g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    if (!solid_at(g, mask, x, y, z + 1)) return;
+    const long long off = cell_off(g, x, y, z + 1);
+    for (int k = 0; k < Q; k++) other[(long long)k * g.plane + off] = cur[(long long)k * g.plane + off];
+}
+
+template <int PRESET>
+__global__ void k_classify(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ cls, Geo g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    unsigned char out[Q];
+    if (solid_at(g, mask, x, y, z + 1)) {
+        for (int k = 0; k < Q; k++) out[k] = SRC_PULL;
+    } else {
+        GatherAll<PRESET, Q - 1>::classify(g, mask, x, y, z + 1, out);
+    }
+    for (int k = 0; k < Q; k++) cls[i * Q + k] = out[k];
+}
+
+// ---- z-slab halo messages -------------------------------------------------------------------
+// message = 5 population layers (layer floats each) followed by `tail` floats of outlet-edge values:
+//   top message   (side 1, from layer zl = D): planes 5,11,14,15,18; tail = f10(W-1,H-1), f9(W-1,H-1), f13(W-1,y) for all y
+//   bottom message(side 0, from layer zl = 1): planes 6,12,13,16,17; tail = f8(W-1,0),  f9(W-1,0)
+// The tails are what the unchecked outlet index of the reference (lbm_solver.cu:292-296) reads
+// across a z face; they land in ghost-layer planes that the regular exchange does not use.
+__device__ __forceinline__ int halo_plane(int side, int j) { return side ? UP5[j] : DOWN5[j]; }
+
+__global__ void k_halo_pack(const float* __restrict__ f, float* __restrict__ msg, Geo g, int side) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int zl = side ? g.D : 1;
+    if (j < 5) {
+        if (i < g.layer) msg[(long long)j * g.layer + i] = f[(long long)halo_plane(side, j) * g.plane + (long long)zl * g.layer + i];
+        return;
+    }
+    float* tail = msg + 5 * g.layer;
+    if (i >= g.H + 2) return;
+    float v = 0.0f;
+    if (side) {
+        if (i == 0) v = f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)];
+        else if (i == 1) v = f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)];
+        else v = f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)];
+    } else {
+        if (i == 0) v = f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)];
+        else if (i == 1) v = f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)];
+    }
+    tail[i] = v;
+}
+
+// side 0: message from the lower neighbour's TOP face -> bottom ghost layer (zl = 0)
+// side 1: message from the upper neighbour's BOTTOM face -> top ghost layer (zl = D+1)
+__global__ void k_halo_unpack(float* __restrict__ f, const float* __restrict__ msg, Geo g, int side) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int zl = side ? g.D + 1 : 0;
+    if (j < 5) {
+        // the message that arrives on our bottom face is the sender's top message (planes UP5)
+        if (i < g.layer) f[(long long)halo_plane(1 - side, j) * g.plane + (long long)zl * g.layer + i] = msg[(long long)j * g.layer + i];
+        return;
+    }
+    const float* tail = msg + 5 * g.layer;
+    if (side == 0) {
+        if (i >= g.H + 2) return;
+        if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
+        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[1];
+        else f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)] = tail[i];
+    } else {
+        if (i == 0) f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[0];
+        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[1];
+    }
+}
+
+// one layer of the packed mask <-> dense u8 (ghost exchange of the static mask)
+__global__ void k_mask_layer_get(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g, int zl) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)g.W * g.H) return;
+    const int y = (int)(i / g.W), x = (int)(i - (long long)y * g.W);
+    dense[i] = solid_at(g, mask, x, y, zl) ? 255 : 0;
+}
+__global__ void k_mask_layer_set(unsigned long long* __restrict__ mask, const unsigned char* __restrict__ dense, Geo g, int zl) {
+    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= (long long)g.H * g.Wm) return;
+    const int y = (int)(wi / g.Wm), xw = (int)(wi - (long long)y * g.Wm);
+    const unsigned char* src = dense + (long long)y * g.W + (long long)xw * 64;
+    const int cnt = min(64, g.W - xw * 64);
+    unsigned long long bits = 0;
+    for (int b = 0; b < cnt; b++) bits |= (unsigned long long)(src[b] > 0) << b;
+    mask[(long long)zl * g.H * g.Wm + wi] = bits;
+}
+
+// k_compute_curl (lbm_solver.cu:612-656): |curl u| by clamped central differences.
+__global__ void k_curl(const float4* __restrict__ u, float* __restrict__ curl, int W, int H, int D) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x >= W) return;
+    auto at = [&](int ix, int iy, int iz) -> float4 {
+        ix = max(0, min(ix, W - 1));
+        iy = max(0, min(iy, H - 1));
+        iz = max(0, min(iz, D - 1));
+        return u[((long long)iz * H + iy) * W + ix];
+    };
+    const float4 xp = at(x + 1, y, z), xm = at(x - 1, y, z);
+    const float4 yp = at(x, y + 1, z), ym = at(x, y - 1, z);
+    const float4 zp = at(x, y, z + 1), zm = at(x, y, z - 1);
+    const float dv_dx = (xp.y - xm.y) * 0.5f;
+    const float dw_dx = (xp.z - xm.z) * 0.5f;
+    const float du_dy = (yp.x - ym.x) * 0.5f;
+    const float dw_dy = (yp.z - ym.z) * 0.5f;
+    const float du_dz = (zp.x - zm.x) * 0.5f;
+    const float dv_dz = (zp.y - zm.y) * 0.5f;
+    const float cxv = dw_dy - dv_dz;
+    const float cyv = du_dz - dw_dx;
+    const float czv = dv_dx - du_dy;
+    curl[((long long)z * H + y) * W + x] = sqrtf(cxv * cxv + cyv * cyv + czv * czv);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+enum FieldState { FIELDS_INIT = 0, FIELDS_STALE = 1, FIELDS_VALID = 2 };
+
+struct lbm_ctx {
+    Geo g{};
+    int device = 0;
+    int preset = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* f[2] = {nullptr, nullptr};
+    int cur = 0;
+    unsigned long long* mask = nullptr;
+    unsigned char* flags = nullptr;
+    float* rho = nullptr;
+    float4* u = nullptr;
+    float* curl = nullptr;
+    Params p{0.08f, 1.98f, 1.90f};  // lbm_solver.cuh:11-13
+    Params p_last{0.08f, 1.98f, 1.90f};
+    bool mask_dirty = true;    // tile flags / solid sync pending
+    FieldState fields = FIELDS_INIT;
+    bool curl_valid = false;
+    int segsx_log2 = 0;
+    int split_phase = 0;       // 0 idle, 1 boundary layers issued, 2 interior issued
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t steps = 0, steps_at_begin = 0;
+    double last_ms = 0.0;
+    uint64_t last_steps = 0;
+    size_t pop_bytes = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(lbm_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), LBM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define NEED(c)                                               \
+    do {                                                      \
+        if (!(c)) return fail(nullptr, LBM_ERR_INVALID, "null context"); \
+        hipError_t e_ = hipSetDevice((c)->device);            \
+        if (e_ != hipSuccess) return fail((c), LBM_ERR_NO_DEVICE, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline long long cells(const lbm_ctx* c) { return (long long)c->g.W * c->g.H * c->g.D; }
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+static int ensure_field_buffers(lbm_ctx* c) {
+    const long long n = cells(c);
+    if (!c->rho) HIPCHK(c, hipMalloc(&c->rho, n * sizeof(float)));
+    if (!c->u) HIPCHK(c, hipMalloc(&c->u, n * sizeof(float4)));
+    return LBM_OK;
+}
+
+// rebuild tile flags and re-freeze solid cells after a mask / population change
+static int refresh_mask_state(lbm_ctx* c) {
+    if (!c->mask_dirty) return LBM_OK;
+    const long long ntiles = (long long)c->g.D * c->g.H * c->g.Wt;
+    if (c->preset == LBM_PRESET_CAVITY)
+        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_CAVITY>, dim3(blocks_for(ntiles, 256)), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
+    else
+        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_WIND_TUNNEL_REF>, dim3(blocks_for(ntiles, 256)), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_sync_solid, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream,
+                       c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
+    HIPCHK(c, hipGetLastError());
+    c->mask_dirty = false;
+    return LBM_OK;
+}
+
+template <int MODE>
+static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers) {
+    if (nlayers <= 0) return LBM_OK;
+    const int segsx = 1 << c->segsx_log2;
+    dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
+    if (c->preset == LBM_PRESET_CAVITY)
+        hipLaunchKernelGGL((k_stream_collide<LBM_PRESET_CAVITY, MODE>), grid, dim3(256), 0, c->stream, fin, fout,
+                           c->mask, c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2);
+    else
+        hipLaunchKernelGGL((k_stream_collide<LBM_PRESET_WIND_TUNNEL_REF, MODE>), grid, dim3(256), 0, c->stream, fin,
+                           fout, c->mask, c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2);
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
+// bring rho/u up to date: what the reference's per-step writes would hold right now
+static int materialise_fields(lbm_ctx* c) {
+    if (c->fields == FIELDS_VALID) return LBM_OK;
+    int rc = ensure_field_buffers(c);
+    if (rc) return rc;
+    if (c->fields == FIELDS_INIT) {
+        hipLaunchKernelGGL(k_fill_fields, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->rho, c->u, cells(c));
+        HIPCHK(c, hipGetLastError());
+    } else {
+        // the last step read f[1-cur]; it is still intact (A/B), so the same gather gives the
+        // same post-stream moments (lbm_solver.cu:320-337)
+        rc = launch_stream_collide<1>(c, c->f[1 - c->cur], nullptr, c->p_last, 1, c->g.D);
+        if (rc) return rc;
+    }
+    c->fields = FIELDS_VALID;
+    c->curl_valid = false;
+    return LBM_OK;
+}
+
+extern "C" {
+
+int lbm_abi_version(void) { return LBM_ABI_VERSION; }
+
+const char* lbm_last_error(lbm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* opts) {
+    if (!out) return fail(nullptr, LBM_ERR_INVALID, "lbm_create: out is null");
+    *out = nullptr;
+    if (width < 1 || height < 1 || depth < 1)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: dimensions must be positive (got %d x %d x %d)", width, height, depth);
+    lbm_opts o;
+    memset(&o, 0, sizeof o);
+    o.device = -1;
+    o.plane_skew_bytes = -1;
+    if (opts) {
+        if (opts->struct_size < (int)offsetof(lbm_opts, reserved) || opts->struct_size > (int)sizeof(lbm_opts))
+            return fail(nullptr, LBM_ERR_INVALID, "lbm_create: lbm_opts.struct_size %d not understood", opts->struct_size);
+        memcpy(&o, opts, (size_t)opts->struct_size);
+    }
+    if (o.preset != LBM_PRESET_WIND_TUNNEL_REF && o.preset != LBM_PRESET_CAVITY)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown preset %d", o.preset);
+    if (o.scheme != LBM_SCHEME_AB) return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
+    int Dg = o.depth_global > 0 ? o.depth_global : depth;
+    int z0 = o.depth_global > 0 ? o.z0 : 0;
+    if (z0 < 0 || (long long)z0 + depth > Dg)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: slab [%d, %d) outside global depth %d", z0, z0 + depth, Dg);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, LBM_ERR_NO_DEVICE, "lbm_create: no HIP device available (this library has no CPU path)");
+    int dev = o.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= ndev) return fail(nullptr, LBM_ERR_NO_DEVICE, "lbm_create: device %d of %d", dev, ndev);
+    if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, LBM_ERR_NO_DEVICE, "lbm_create: hipSetDevice(%d) failed", dev);
+
+    lbm_ctx* c = new lbm_ctx();
+    c->device = dev;
+    c->preset = o.preset;
+    Geo& g = c->g;
+    g.W = width; g.H = height; g.D = depth; g.Dg = Dg; g.z0 = z0;
+    g.slab = o.depth_global > 0 ? 1 : 0;
+    g.Wp = (width + 31) / 32 * 32;
+    g.Wm = (width + 63) / 64;
+    g.Wt = g.Wm;
+    g.layer = (long long)height * g.Wp;
+    long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 4352) / 4;  // 4 KiB + 256 B
+    skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
+    g.plane = (long long)(depth + 2) * g.layer + skew_floats;
+    c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
+    c->pop_bytes = (size_t)Q * g.plane * sizeof(float);
+
+    auto cleanup = [&](int code) {
+        lbm_destroy(c);
+        return code;
+    };
+#define CR(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fail(nullptr, LBM_ERR_HIP, "lbm_create: %s failed: %s", #call, hipGetErrorString(e_)); \
+            return cleanup(LBM_ERR_HIP);                                                           \
+        }                                                                                          \
+    } while (0)
+    if (o.stream) {
+        c->stream = (hipStream_t)o.stream;
+    } else {
+        CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    CR(hipMalloc(&c->f[0], c->pop_bytes));
+    CR(hipMalloc(&c->f[1], c->pop_bytes));
+    const size_t mask_bytes = (size_t)(depth + 2) * height * g.Wm * sizeof(unsigned long long);
+    CR(hipMalloc(&c->mask, mask_bytes));
+    CR(hipMemsetAsync(c->mask, 0, mask_bytes, c->stream));  // d_solid.memset(0), lbm_solver.cu:415
+    CR(hipMalloc(&c->flags, (size_t)depth * height * g.Wt));
+    CR(hipEventCreate(&c->ev0));
+    CR(hipEventCreate(&c->ev1));
+#undef CR
+    *out = c;
+    return LBM_OK;
+}
+
+int lbm_destroy(lbm_ctx* c) {
+    if (!c) return LBM_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->f[0]); hipFree(c->f[1]); hipFree(c->mask); hipFree(c->flags);
+    hipFree(c->rho); hipFree(c->u); hipFree(c->curl);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return LBM_OK;
+}
+
+int lbm_init(lbm_ctx* c) {
+    NEED(c);
+    const long long count = (long long)(c->g.D + 2) * c->g.layer;
+    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(count, 256), Q), dim3(256), 0, c->stream, c->f[0], c->f[1], c->g.plane, count);
+    HIPCHK(c, hipGetLastError());
+    c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
+    c->curl_valid = false;
+    return LBM_OK;
+}
+
+int lbm_set_params(lbm_ctx* c, float inlet_velocity, float omega_shear, float omega_bulk) {
+    if (!c) return fail(nullptr, LBM_ERR_INVALID, "null context");
+    c->p.U = inlet_velocity; c->p.omega_shear = omega_shear; c->p.omega_bulk = omega_bulk;
+    return LBM_OK;
+}
+
+int lbm_get_params(lbm_ctx* c, float* inlet_velocity, float* omega_shear, float* omega_bulk) {
+    if (!c) return fail(nullptr, LBM_ERR_INVALID, "null context");
+    if (inlet_velocity) *inlet_velocity = c->p.U;
+    if (omega_shear) *omega_shear = c->p.omega_shear;
+    if (omega_bulk) *omega_bulk = c->p.omega_bulk;
+    return LBM_OK;
+}
+
+// the fields the reference would hold were written with the OLD mask: settle them first
+static int before_mask_change(lbm_ctx* c) {
+    if (c->fields == FIELDS_STALE) {
+        int rc = refresh_mask_state(c);
+        if (rc) return rc;
+        return materialise_fields(c);
+    }
+    return LBM_OK;
+}
+
+int lbm_add_solid_rect(lbm_ctx* c, int x, int y, int z, int w, int h, int d) {
+    NEED(c);
+    int rc = before_mask_change(c);
+    if (rc) return rc;
+    const long long nwords = (long long)(c->g.D + 2) * c->g.H * c->g.Wm;
+    hipLaunchKernelGGL(k_add_rect, dim3(blocks_for(nwords, 256)), dim3(256), 0, c->stream, c->mask, c->g, x, y, z, w, h, d);
+    HIPCHK(c, hipGetLastError());
+    c->mask_dirty = true;
+    return LBM_OK;
+}
+
+int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
+    NEED(c);
+    if (!mask) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8: mask is null");
+    if (n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8: expected %lld cells, got %zu", cells(c), n);
+    int rc = before_mask_change(c);
+    if (rc) return rc;
+    unsigned char* dense = nullptr;
+    HIPCHK(c, hipMalloc(&dense, n));
+    hipError_t e = hipMemcpyAsync(dense, mask, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const long long nwords = (long long)c->g.D * c->g.H * c->g.Wm;
+        hipLaunchKernelGGL(k_pack_mask, dim3(blocks_for(nwords, 256)), dim3(256), 0, c->stream, dense, c->mask, c->g);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dense);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_set_solid_u8: %s", hipGetErrorString(e));
+    c->mask_dirty = true;
+    return LBM_OK;
+}
+
+int lbm_load_mesh(lbm_ctx* c, const char* obj_path) {
+    NEED(c);
+    if (!obj_path) return fail(c, LBM_ERR_INVALID, "lbm_load_mesh: path is null");
+    if (c->g.Dg != c->g.D)
+        return fail(c, LBM_ERR_STATE, "lbm_load_mesh: voxelise the global domain once and hand each slab its layers with lbm_set_solid_u8");
+    std::vector<uint8_t> host;
+    float scale = 0.0f;
+    const bool loaded = lbmvox::build_wind_tunnel_mask(obj_path, c->g.W, c->g.H, c->g.D, host, &scale);
+    int rc = lbm_set_solid_u8(c, host.data(), host.size());
+    if (rc) return rc;
+    if (!loaded) return fail(c, LBM_ERR_IO, "lbm_load_mesh: cannot read '%s' (floor-only mask installed, as the reference leaves it)", obj_path);
+    return LBM_OK;
+}
+
+int lbm_step(lbm_ctx* c, int nsteps) {
+    NEED(c);
+    if (nsteps < 0) return fail(c, LBM_ERR_INVALID, "lbm_step: nsteps %d", nsteps);
+    if (nsteps == 0) return LBM_OK;
+    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step: a split step is in flight (lbm_step_finish missing)");
+    int rc = refresh_mask_state(c);
+    if (rc) return rc;
+    for (int s = 0; s < nsteps; s++) {
+        rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D);
+        if (rc) return rc;
+        c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
+    }
+    c->p_last = c->p;
+    c->steps += (uint64_t)nsteps;
+    c->fields = FIELDS_STALE;
+    c->curl_valid = false;
+    return LBM_OK;
+}
+
+int lbm_compute_curl(lbm_ctx* c) {
+    NEED(c);
+    int rc = refresh_mask_state(c);
+    if (rc) return rc;
+    rc = materialise_fields(c);
+    if (rc) return rc;
+    if (c->curl_valid) return LBM_OK;
+    if (!c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
+    dim3 grid((c->g.W + 255) / 256, c->g.H, c->g.D);
+    hipLaunchKernelGGL(k_curl, grid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
+    HIPCHK(c, hipGetLastError());
+    c->curl_valid = true;
+    return LBM_OK;
+}
+
+int lbm_sync(lbm_ctx* c) {
+    NEED(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+static int read_back(lbm_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+int lbm_read_density(lbm_ctx* c, float* rho, size_t n) {
+    NEED(c);
+    if (!rho || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_density: need %lld floats", cells(c));
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = materialise_fields(c);
+    if (rc) return rc;
+    return read_back(c, rho, c->rho, n * sizeof(float));
+}
+
+int lbm_read_velocity(lbm_ctx* c, float* u, size_t n) {
+    NEED(c);
+    if (!u || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity: need %lld x 4 floats", cells(c));
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = materialise_fields(c);
+    if (rc) return rc;
+    return read_back(c, u, c->u, n * sizeof(float4));
+}
+
+int lbm_read_curl(lbm_ctx* c, float* curl, size_t n) {
+    NEED(c);
+    if (!curl || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_curl: need %lld floats", cells(c));
+    int rc = lbm_compute_curl(c);
+    if (rc) return rc;
+    return read_back(c, curl, c->curl, n * sizeof(float));
+}
+
+int lbm_read_solid_u8(lbm_ctx* c, uint8_t* mask, size_t n) {
+    NEED(c);
+    if (!mask || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_solid_u8: need %lld bytes", cells(c));
+    unsigned char* dense = nullptr;
+    HIPCHK(c, hipMalloc(&dense, n));
+    hipLaunchKernelGGL(k_unpack_mask, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, dense, c->g);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(mask, dense, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dense);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_read_solid_u8: %s", hipGetErrorString(e));
+    return LBM_OK;
+}
+
+int lbm_read_classification(lbm_ctx* c, uint8_t* cls, size_t n19) {
+    NEED(c);
+    const size_t n = (size_t)cells(c);
+    if (!cls || n19 != n * Q) return fail(c, LBM_ERR_INVALID, "lbm_read_classification: need %zu bytes", n * Q);
+    unsigned char* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n19));
+    if (c->preset == LBM_PRESET_CAVITY)
+        hipLaunchKernelGGL(k_classify<LBM_PRESET_CAVITY>, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, d, c->g);
+    else
+        hipLaunchKernelGGL(k_classify<LBM_PRESET_WIND_TUNNEL_REF>, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, d, c->g);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(cls, d, n19, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_read_classification: %s", hipGetErrorString(e));
+    return LBM_OK;
+}
+
+// populations <-> reference layout: one strided 2-D copy per plane (rows of W floats out of Wp)
+static int copy_populations(lbm_ctx* c, float* host, bool to_host) {
+    const Geo& g = c->g;
+    const size_t n = (size_t)cells(c);
+    for (int k = 0; k < Q; k++) {
+        float* dev = c->f[c->cur] + (long long)k * g.plane + g.layer;  // first owned layer
+        float* h = host + (size_t)k * n;
+        if (to_host)
+            HIPCHK(c, hipMemcpy2DAsync(h, (size_t)g.W * 4, dev, (size_t)g.Wp * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyDeviceToHost, c->stream));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dev, (size_t)g.Wp * 4, h, (size_t)g.W * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LBM_OK;
+}
+
+int lbm_read_populations(lbm_ctx* c, float* f, size_t n19) {
+    NEED(c);
+    if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_read_populations: need %lld floats", cells(c) * Q);
+    return copy_populations(c, f, true);
+}
+
+int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
+    NEED(c);
+    if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_write_populations: need %lld floats", cells(c) * Q);
+    int rc = LBM_OK;
+    if (c->fields == FIELDS_STALE) {  // settle rho/u of the last step before touching solid cells
+        rc = refresh_mask_state(c);
+        if (!rc) rc = materialise_fields(c);
+        if (rc) return rc;
+    }
+    rc = copy_populations(c, const_cast<float*>(f), false);
+    if (rc) return rc;
+    c->mask_dirty = true;  // solid cells of the other buffer must follow
+    return LBM_OK;
+}
+
+int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl) {
+    NEED(c);
+    int rc = lbm_compute_curl(c);
+    if (rc) return rc;
+    if (d_rho) *d_rho = c->rho;
+    if (d_u) *d_u = reinterpret_cast<float*>(c->u);
+    if (d_curl) *d_curl = c->curl;
+    return LBM_OK;
+}
+
+int lbm_get_dims(lbm_ctx* c, int* w, int* h, int* d) {
+    if (!c) return fail(nullptr, LBM_ERR_INVALID, "null context");
+    if (w) *w = c->g.W;
+    if (h) *h = c->g.H;
+    if (d) *d = c->g.D;
+    return LBM_OK;
+}
+
+int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
+    if (!c || !out) return fail(c, LBM_ERR_INVALID, "lbm_get_stats: null argument");
+    out->steps = c->steps;
+    out->cells = (uint64_t)cells(c);
+    out->bytes_per_cell = 2ull * Q * sizeof(float);
+    out->population_bytes = 2ull * c->pop_bytes;
+    out->last_timed_ms = c->last_ms;
+    out->last_timed_steps = c->last_steps;
+    return LBM_OK;
+}
+
+int lbm_timer_begin(lbm_ctx* c) {
+    NEED(c);
+    int rc = refresh_mask_state(c);  // keep one-off set-up kernels out of the timed region
+    if (rc) return rc;
+    c->steps_at_begin = c->steps;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return LBM_OK;
+}
+
+int lbm_timer_end(lbm_ctx* c) {
+    NEED(c);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    c->last_steps = c->steps - c->steps_at_begin;
+    return LBM_OK;
+}
+
+// ---- z-slab API ---------------------------------------------------------------------------
+static inline size_t halo_tail_floats(const lbm_ctx* c) { return (size_t)((c->g.H + 2 + 31) / 32 * 32); }
+
+int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
+    if (!c || !nfloats) return fail(c, LBM_ERR_INVALID, "lbm_halo_message_floats: null argument");
+    *nfloats = 5 * (size_t)c->g.layer + halo_tail_floats(c);
+    return LBM_OK;
+}
+
+static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
+    if (!c->g.slab) return fail(c, LBM_ERR_STATE, "%s: context was not created as a slab (lbm_opts.depth_global = 0)", who);
+    if (side != 0 && side != 1) return fail(c, LBM_ERR_INVALID, "%s: side must be 0 or 1", who);
+    if (!p) return fail(c, LBM_ERR_INVALID, "%s: buffer is null", who);
+    return LBM_OK;
+}
+
+int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
+    NEED(c);
+    int rc = halo_args_ok(c, side, d_message, "lbm_halo_pack");
+    if (rc) return rc;
+    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    // after lbm_step_interior_layers the new state is still f[1-cur] until lbm_step_finish
+    const float* src = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, src, d_message, c->g, side);
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
+int lbm_halo_unpack(lbm_ctx* c, int side, const float* d_message) {
+    NEED(c);
+    int rc = halo_args_ok(c, side, d_message, "lbm_halo_unpack");
+    if (rc) return rc;
+    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, dst, d_message, c->g, side);
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
+int lbm_halo_get_mask_layer(lbm_ctx* c, int side, uint8_t* layer, size_t n) {
+    NEED(c);
+    int rc = halo_args_ok(c, side, layer, "lbm_halo_get_mask_layer");
+    if (rc) return rc;
+    const size_t wh = (size_t)c->g.W * c->g.H;
+    if (n != wh) return fail(c, LBM_ERR_INVALID, "lbm_halo_get_mask_layer: need %zu bytes", wh);
+    unsigned char* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, wh));
+    hipLaunchKernelGGL(k_mask_layer_get, dim3(blocks_for((long long)wh, 256)), dim3(256), 0, c->stream, c->mask, d, c->g, side ? c->g.D : 1);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(layer, d, wh, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_halo_get_mask_layer: %s", hipGetErrorString(e));
+    return LBM_OK;
+}
+
+int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n) {
+    NEED(c);
+    int rc = halo_args_ok(c, side, layer, "lbm_halo_set_mask_ghost");
+    if (rc) return rc;
+    const size_t wh = (size_t)c->g.W * c->g.H;
+    if (n != wh) return fail(c, LBM_ERR_INVALID, "lbm_halo_set_mask_ghost: need %zu bytes", wh);
+    rc = before_mask_change(c);
+    if (rc) return rc;
+    unsigned char* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, wh));
+    hipError_t e = hipMemcpyAsync(d, layer, wh, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mask_layer_set, dim3(blocks_for((long long)c->g.H * c->g.Wm, 256)), dim3(256), 0, c->stream, c->mask, d, c->g, side ? c->g.D + 1 : 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_halo_set_mask_ghost: %s", hipGetErrorString(e));
+    c->mask_dirty = true;
+    return LBM_OK;
+}
+
+int lbm_step_boundary_layers(lbm_ctx* c) {
+    NEED(c);
+    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
+    int rc = refresh_mask_state(c);
+    if (rc) return rc;
+    rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, 1);
+    if (!rc && c->g.D > 1) rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, c->g.D, 1);
+    if (rc) return rc;
+    c->split_phase = 1;
+    return LBM_OK;
+}
+
+int lbm_step_interior_layers(lbm_ctx* c) {
+    NEED(c);
+    if (c->split_phase != 1) return fail(c, LBM_ERR_STATE, "lbm_step_interior_layers: call lbm_step_boundary_layers first");
+    int rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 2, c->g.D - 2);
+    if (rc) return rc;
+    c->split_phase = 2;
+    return LBM_OK;
+}
+
+int lbm_step_finish(lbm_ctx* c) {
+    NEED(c);
+    if (c->split_phase != 2) return fail(c, LBM_ERR_STATE, "lbm_step_finish: call lbm_step_interior_layers first");
+    c->cur = 1 - c->cur;
+    c->p_last = c->p;
+    c->steps += 1;
+    c->fields = FIELDS_STALE;
+    c->curl_valid = false;
+    c->split_phase = 0;
+    return LBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+"""ctypes binding of liblbm_hip.so (include/lbm_abi.h) and a Python mirror of the reference's
+`lbm_solver` class (Engine/src/Physics/lbm_solver.cuh:17-51).
+
+This is host-side plumbing for tests and bench.py; the C++ mirror a maintainer would compile into
+the engine is cfd_amd/csrc/lbm_solver.hpp.  There is no CPU path here: without the HIP library or
+without a GPU every compute call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+Q = 19
+PRESET_WIND_TUNNEL = 0
+PRESET_CAVITY = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
+
+
+class LbmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lbm error {code}: {msg}")
+        self.code = code
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("preset", C.c_int32),
+                ("scheme", C.c_int32), ("z0", C.c_int32), ("depth_global", C.c_int32),
+                ("stream", C.c_void_p), ("plane_skew_bytes", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("cells", C.c_uint64), ("bytes_per_cell", C.c_uint64),
+                ("population_bytes", C.c_uint64), ("last_timed_ms", C.c_double),
+                ("last_timed_steps", C.c_uint64)]
+
+
+# every symbol include/lbm_abi.h declares, with its ctypes signature
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint8)
+_ctx = C.c_void_p
+SIGNATURES = {
+    "lbm_create": ([C.POINTER(_ctx), C.c_int, C.c_int, C.c_int, C.POINTER(Opts)], C.c_int),
+    "lbm_destroy": ([_ctx], C.c_int),
+    "lbm_init": ([_ctx], C.c_int),
+    "lbm_set_params": ([_ctx, C.c_float, C.c_float, C.c_float], C.c_int),
+    "lbm_get_params": ([_ctx, _fp, _fp, _fp], C.c_int),
+    "lbm_add_solid_rect": ([_ctx] + [C.c_int] * 6, C.c_int),
+    "lbm_set_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
+    "lbm_load_mesh": ([_ctx, C.c_char_p], C.c_int),
+    "lbm_step": ([_ctx, C.c_int], C.c_int),
+    "lbm_compute_curl": ([_ctx], C.c_int),
+    "lbm_sync": ([_ctx], C.c_int),
+    "lbm_read_density": ([_ctx, _fp, C.c_size_t], C.c_int),
+    "lbm_read_velocity": ([_ctx, _fp, C.c_size_t], C.c_int),
+    "lbm_read_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
+    "lbm_read_curl": ([_ctx, _fp, C.c_size_t], C.c_int),
+    "lbm_read_populations": ([_ctx, _fp, C.c_size_t], C.c_int),
+    "lbm_write_populations": ([_ctx, _fp, C.c_size_t], C.c_int),
+    "lbm_read_classification": ([_ctx, _up, C.c_size_t], C.c_int),
+    "lbm_device_fields": ([_ctx, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp)], C.c_int),
+    "lbm_get_dims": ([_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "lbm_get_stats": ([_ctx, C.POINTER(Stats)], C.c_int),
+    "lbm_timer_begin": ([_ctx], C.c_int),
+    "lbm_timer_end": ([_ctx], C.c_int),
+    "lbm_last_error": ([_ctx], C.c_char_p),
+    "lbm_abi_version": ([], C.c_int),
+    "lbm_halo_message_floats": ([_ctx, C.POINTER(C.c_size_t)], C.c_int),
+    "lbm_halo_pack": ([_ctx, C.c_int, C.c_void_p], C.c_int),
+    "lbm_halo_unpack": ([_ctx, C.c_int, C.c_void_p], C.c_int),
+    "lbm_halo_get_mask_layer": ([_ctx, C.c_int, _up, C.c_size_t], C.c_int),
+    "lbm_halo_set_mask_ghost": ([_ctx, C.c_int, _up, C.c_size_t], C.c_int),
+    "lbm_step_boundary_layers": ([_ctx], C.c_int),
+    "lbm_step_interior_layers": ([_ctx], C.c_int),
+    "lbm_step_finish": ([_ctx], C.c_int),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is None or path is not None:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise FileNotFoundError(
+                f"{p} is missing: build it with `make -C cfd_amd/csrc` (or __graft_entry__.build()); "
+                "the hot path has no CPU fallback")
+        lib = C.CDLL(p)
+        for name, (args, res) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = lib
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _u(a):
+    return a.ctypes.data_as(_up)
+
+
+class Solver:
+    """Mirror of `lbm_solver` (lbm_solver.cuh:17-51): ctor(W,H,D), init, step, reset,
+    compute_curl, add_solid, load_mesh, density / velocity / solid-mask read-back, settings."""
+
+    def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
+                 stream=None, plane_skew_bytes=-1):
+        self._lib = load_library()
+        self.W, self.H, self.D = W, H, D
+        self.n = W * H * D
+        self.preset = preset
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.device = device
+        o.preset = preset
+        o.scheme = 0
+        o.z0 = z0
+        o.depth_global = depth_global
+        o.stream = stream
+        o.plane_skew_bytes = plane_skew_bytes
+        self._ctx = _ctx()
+        rc = self._lib.lbm_create(C.byref(self._ctx), W, H, D, C.byref(o))
+        if rc != 0:
+            msg = self._lib.lbm_last_error(None)
+            self._ctx = None
+            raise LbmError(rc, msg.decode() if msg else "?")
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._lib.lbm_last_error(self._ctx)
+            raise LbmError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.lbm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference surface ---------------------------------------------------------------
+    def init(self):
+        self._chk(self._lib.lbm_init(self._ctx))
+
+    reset = init  # lbm_solver.cu:496
+
+    def set_params(self, inlet_velocity=None, omega_shear=None, omega_bulk=None):
+        u, ws, wb = self.params()
+        self._chk(self._lib.lbm_set_params(
+            self._ctx,
+            u if inlet_velocity is None else inlet_velocity,
+            ws if omega_shear is None else omega_shear,
+            wb if omega_bulk is None else omega_bulk))
+
+    def params(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        self._chk(self._lib.lbm_get_params(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def step(self, nsteps=1):
+        self._chk(self._lib.lbm_step(self._ctx, nsteps))
+
+    def compute_curl(self):
+        self._chk(self._lib.lbm_compute_curl(self._ctx))
+
+    def add_solid(self, x, y, z, w, h, d):
+        self._chk(self._lib.lbm_add_solid_rect(self._ctx, x, y, z, w, h, d))
+
+    def set_solid(self, mask_u8):
+        m = np.ascontiguousarray(mask_u8, np.uint8).reshape(-1)
+        self._chk(self._lib.lbm_set_solid_u8(self._ctx, _u(m), m.size))
+
+    def load_mesh(self, path):
+        self._chk(self._lib.lbm_load_mesh(self._ctx, os.fsencode(path)))
+
+    def sync(self):
+        self._chk(self._lib.lbm_sync(self._ctx))
+
+    def density(self):
+        out = np.empty(self.n, np.float32)
+        self._chk(self._lib.lbm_read_density(self._ctx, _f(out), out.size))
+        return out
+
+    def velocity(self):
+        out = np.empty((self.n, 4), np.float32)
+        self._chk(self._lib.lbm_read_velocity(self._ctx, _f(out), self.n))
+        return out
+
+    def solid_mask(self):
+        out = np.empty(self.n, np.uint8)
+        self._chk(self._lib.lbm_read_solid_u8(self._ctx, _u(out), out.size))
+        return out
+
+    def curl_field(self):
+        out = np.empty(self.n, np.float32)
+        self._chk(self._lib.lbm_read_curl(self._ctx, _f(out), out.size))
+        return out
+
+    def populations(self):
+        out = np.empty((Q, self.n), np.float32)
+        self._chk(self._lib.lbm_read_populations(self._ctx, _f(out), out.size))
+        return out
+
+    def set_populations(self, f):
+        a = np.ascontiguousarray(f, np.float32).reshape(-1)
+        self._chk(self._lib.lbm_write_populations(self._ctx, _f(a), a.size))
+
+    def classification(self):
+        cls = np.empty((self.n, Q), np.uint8)
+        self._chk(self._lib.lbm_read_classification(self._ctx, _u(cls), cls.size))
+        return cls
+
+    # -- measurement ---------------------------------------------------------------------
+    def stats(self):
+        s = Stats()
+        self._chk(self._lib.lbm_get_stats(self._ctx, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def timer_begin(self):
+        self._chk(self._lib.lbm_timer_begin(self._ctx))
+
+    def timer_end(self):
+        self._chk(self._lib.lbm_timer_end(self._ctx))
+        return self.stats()["last_timed_ms"]

@@ -1,0 +1,174 @@
+/*
+ * lbm_abi.h -- C ABI of the MI355X-native D3Q19 lattice-Boltzmann hot path (liblbm_hip.so).
+ *
+ * The reference (1neskk/CFD) has no FFI: its solver is a C++ class compiled into the engine
+ * (Engine/src/Physics/lbm_solver.cuh:17-80).  Each entry point below replaces one member of that
+ * class (cited as file:line into the reference); the header-only C++ class
+ * cfd_amd/csrc/lbm_solver.hpp puts the reference's own names back on top of this ABI so the
+ * engine's `cfd` layer (Engine/src/main.cpp:17-28,36) keeps compiling against it headless.
+ *
+ * Conventions
+ *   - plain C: opaque context pointer, ints, floats, raw host pointers and byte/element counts.
+ *   - every call returns 0 on success or a negative lbm_status; lbm_last_error() gives the text.
+ *   - a context is bound to one HIP device and one stream; it is not thread-safe.
+ *   - host arrays use the reference's wire formats, x fastest: idx = z*W*H + y*W + x
+ *     (lbm_solver.cu:253): density float[n], velocity float[n][4] = (ux,uy,uz,0)
+ *     (cuda_math.cuh:37-55, lbm_solver.cu:337), solid uint8[n] with nonzero = solid (255 written,
+ *     lbm_solver.cu:511), curl float[n].
+ *   - lbm_step() is asynchronous on the context's stream like the reference's launches
+ *     (lbm_solver.cu:482-493); read-backs and lbm_sync() synchronise.
+ *   - there is no CPU fallback: every compute entry point fails with LBM_ERR_NO_DEVICE when no
+ *     HIP device is usable.
+ */
+#ifndef LBM_ABI_H
+#define LBM_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_ABI_VERSION 1
+#define LBM_Q 19
+
+typedef struct lbm_ctx lbm_ctx;
+
+typedef enum lbm_status {
+    LBM_OK = 0,
+    LBM_ERR_INVALID = -1,    /* bad argument (null pointer, non-positive size, count mismatch) */
+    LBM_ERR_NO_DEVICE = -2,  /* no usable HIP device */
+    LBM_ERR_HIP = -3,        /* a HIP runtime call failed; see lbm_last_error */
+    LBM_ERR_IO = -4,         /* mesh file could not be read */
+    LBM_ERR_STATE = -5       /* call not valid in the current state (e.g. slab call on a non-slab ctx) */
+} lbm_status;
+
+/* Boundary presets.  WIND_TUNNEL_REF is the reference's hard-wired chain
+ * (lbm_solver.cu:283-318: inlet x<0, outlet x>=W, floor bounce-back, ceiling reflect_y,
+ * side reflect_z, solid bounce-back, in that order, quirks included).  CAVITY is a closed box
+ * with a lid at y=H-1 moving in +x with `inlet_velocity`; it is NOT in the reference and exists
+ * for the pure-roofline configuration (BASELINE.json configs[1]). */
+enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
+
+/* Streaming schemes.  AB = pull, two population buffers (lbm_solver.cu:482-490). */
+enum { LBM_SCHEME_AB = 0 };
+
+typedef struct lbm_opts {
+    int32_t struct_size;   /* = sizeof(lbm_opts); lets the ABI grow */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    int32_t preset;        /* LBM_PRESET_* */
+    int32_t scheme;        /* LBM_SCHEME_* */
+    /* z-slab decomposition (multi-GPU): this context owns global layers [z0, z0+d) of a domain
+     * that is depth_global deep.  depth_global = 0 means "not decomposed" (z0 = 0, depth = d). */
+    int32_t z0;
+    int32_t depth_global;
+    void*   stream;        /* hipStream_t to run on; NULL = the context creates its own */
+    int32_t plane_skew_bytes; /* extra bytes between population planes; -1 = library default */
+    int32_t reserved[7];
+} lbm_opts;
+
+/* Per-context counters for benches (device time is measured with HIP events on the
+ * context's stream around the lbm_step calls issued between timer_begin and timer_end). */
+typedef struct lbm_stats {
+    uint64_t steps;             /* steps issued since create */
+    uint64_t cells;             /* W*H*D owned by this context */
+    uint64_t bytes_per_cell;    /* algorithmic bytes per cell update of the step kernel (152) */
+    uint64_t population_bytes;  /* device bytes held by the population buffers */
+    double   last_timed_ms;     /* device ms between the last timer_begin/timer_end pair */
+    uint64_t last_timed_steps;  /* steps issued between them */
+} lbm_stats;
+
+/* lbm_solver::lbm_solver(int,int,int)  -- lbm_solver.cu:404-453.  opts may be NULL. */
+int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* opts);
+/* lbm_solver::~lbm_solver  -- lbm_solver.cu:455-469 */
+int lbm_destroy(lbm_ctx* ctx);
+
+/* lbm_solver::init / reset  -- lbm_solver.cu:471-475, 496 (k_init :37-64): f_k = w_k, rho = 1,
+ * u = 0; the solid mask is kept. */
+int lbm_init(lbm_ctx* ctx);
+
+/* settings{inlet_velocity, omega_shear, omega_bulk} -- lbm_solver.cuh:9-15, read at every launch
+ * (lbm_solver.cu:485-486).  `tau` is dead in the reference and has no counterpart. */
+int lbm_set_params(lbm_ctx* ctx, float inlet_velocity, float omega_shear, float omega_bulk);
+int lbm_get_params(lbm_ctx* ctx, float* inlet_velocity, float* omega_shear, float* omega_bulk);
+
+/* lbm_solver::add_solid(Rect) -- lbm_solver.cu:498-519: half-open box, sets, never clears. */
+int lbm_add_solid_rect(lbm_ctx* ctx, int x, int y, int z, int w, int h, int d);
+/* d_solid.copy_from_host -- cuda_buffer.cuh:72-77 as used at lbm_solver.cu:555: replaces the
+ * whole mask (nonzero = solid).  For a slab context `n` is the slab's own W*H*depth cells. */
+int lbm_set_solid_u8(lbm_ctx* ctx, const uint8_t* mask, size_t n);
+/* lbm_solver::load_mesh -- lbm_solver.cu:521-556 + MeshVoxelizer (mesh_voxelizer.cpp:20-246):
+ * OBJ -> rotate_y(-90) -> 0.8 auto-scale -> +X ray-cast voxelisation -> y=0 plane solid ->
+ * whole mask replaced.  A missing file returns LBM_ERR_IO after installing the floor-only mask,
+ * which is what the reference's "log and carry on" leaves behind (:522-524). */
+int lbm_load_mesh(lbm_ctx* ctx, const char* obj_path);
+
+/* lbm_solver::step -- lbm_solver.cu:477-494: `nsteps` fused stream-collide updates with the A/B
+ * swap.  rho/u/curl are not rewritten every step; they are materialised, bit-identical to what
+ * the reference's per-step writes would hold, when read (lbm_read_*, lbm_device_fields). */
+int lbm_step(lbm_ctx* ctx, int nsteps);
+/* lbm_solver::compute_curl -- lbm_solver.cu:612-661 */
+int lbm_compute_curl(lbm_ctx* ctx);
+/* cudaDeviceSynchronize of the debug build / renderer -- lbm_solver.cu:491-493 */
+int lbm_sync(lbm_ctx* ctx);
+
+/* get_density().copy_to_host etc. -- lbm_solver.cuh:40-46 + cuda_buffer.cuh:79-84.
+ * `n` is the element count of the host array and must equal W*H*depth of this context. */
+int lbm_read_density(lbm_ctx* ctx, float* rho, size_t n);
+int lbm_read_velocity(lbm_ctx* ctx, float* u_xyzw, size_t n);
+int lbm_read_solid_u8(lbm_ctx* ctx, uint8_t* mask, size_t n);
+int lbm_read_curl(lbm_ctx* ctx, float* curl, size_t n);
+/* Current populations in the reference layout f[k*n + idx] (d_f, lbm_solver.cuh:62). */
+int lbm_read_populations(lbm_ctx* ctx, float* f, size_t n_times_19);
+int lbm_write_populations(lbm_ctx* ctx, const float* f, size_t n_times_19);
+/* Which branch of lbm_solver.cu:283-318 feeds each direction of each cell: cls[idx*19 + k] in
+ * {0 pull, 1 inlet, 2 outlet, 3 floor-BB, 4 ceiling reflect_y, 5 side reflect_z, 6 solid-BB,
+ *  7 wall-BB (cavity), 8 lid-BB (cavity)}; 0 for every k of a solid cell. */
+int lbm_read_classification(lbm_ctx* ctx, uint8_t* cls, size_t n_times_19);
+
+/* Device pointers of the materialised fields in the reference wire formats, for consumers that
+ * stay on the GPU (the reference hands d_u/d_solid to its renderer, lbm_solver.cuh:40-46). */
+int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_curl);
+
+int lbm_get_dims(lbm_ctx* ctx, int* w, int* h, int* d);
+int lbm_get_stats(lbm_ctx* ctx, lbm_stats* out);
+int lbm_timer_begin(lbm_ctx* ctx);
+int lbm_timer_end(lbm_ctx* ctx);   /* synchronises the stream and fills last_timed_* */
+const char* lbm_last_error(lbm_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+int lbm_abi_version(void);
+
+/* ---- z-slab halo exchange (multi-GPU; the reference is single-GPU) ----
+ * A context created with lbm_opts.depth_global > 0 is one z-slab of a taller domain.  After each
+ * step it sends the five populations that cross its top face (k = 5,11,14,15,18) from its top
+ * owned layer to the upper neighbour's bottom ghost layer, and the five that cross its bottom
+ * face (k = 6,12,13,16,17) from its bottom owned layer to the lower neighbour's top ghost layer.
+ * One population layer is one contiguous run of floats, so a message is five such runs plus a
+ * short tail with the outlet-edge values that the reference's unchecked outlet index reads across
+ * a face (quirk Q2, lbm_solver.cu:292-296).  Because that index also wraps from the last layer to
+ * the first, the wind-tunnel preset exchanges around a RING: rank r sends its top message to
+ * (r+1) mod P and its bottom message to (r-1) mod P; the cavity preset needs only the open chain.
+ *   side: 0 = bottom face (towards z-1), 1 = top face (towards z+1).
+ * lbm_halo_pack gathers this slab's outgoing message for `side` into caller-owned DEVICE memory
+ * of lbm_halo_message_floats() floats; lbm_halo_unpack scatters the message received from the
+ * neighbour on `side` into that side's ghost layer.  The transport in between is the caller's
+ * (RCCL send/recv via torch.distributed in cfd_amd/slab.py; a device copy in single-GPU tests).
+ * Both run on the context's stream. */
+int lbm_halo_message_floats(lbm_ctx* ctx, size_t* nfloats);
+int lbm_halo_pack(lbm_ctx* ctx, int side, float* d_message);
+int lbm_halo_unpack(lbm_ctx* ctx, int side, const float* d_message);
+/* Static ghost layers of the solid mask (exchanged once after the mask changes): this slab's own
+ * boundary layer on `side` as uint8[W*H], and the neighbour's layer to install as the ghost. */
+int lbm_halo_get_mask_layer(lbm_ctx* ctx, int side, uint8_t* layer, size_t n);
+int lbm_halo_set_mask_ghost(lbm_ctx* ctx, int side, const uint8_t* layer, size_t n);
+/* One step split for overlap: the two boundary layers first (their results feed the messages),
+ * then the interior layers while the messages travel, then the A/B swap.
+ * lbm_step(ctx, 1) == boundary + interior + finish. */
+int lbm_step_boundary_layers(lbm_ctx* ctx);
+int lbm_step_interior_layers(lbm_ctx* ctx);
+int lbm_step_finish(lbm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_ABI_H */
