@@ -960,6 +960,24 @@ int lbm_timer_end(lbm_ctx* c) {
     return LBM_OK;
 }
 
+// ---- host-only entry points (no device needed) -----------------------------------------------
+int lbm_host_voxelize_obj(const char* obj_path, int width, int height, int depth, uint8_t* mask, size_t n, float* scale_out) {
+    if (!obj_path || !mask || width < 1 || height < 1 || depth < 1 || n != (size_t)width * height * depth)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_host_voxelize_obj: bad argument");
+    std::vector<uint8_t> host;
+    const bool loaded = lbmvox::build_wind_tunnel_mask(obj_path, width, height, depth, host, scale_out);
+    memcpy(mask, host.data(), n);
+    return loaded ? LBM_OK : fail(nullptr, LBM_ERR_IO, "lbm_host_voxelize_obj: cannot read '%s'", obj_path);
+}
+
+int lbm_host_collide_cell(const float* f19, float omega_shear, float omega_bulk, float* out19, float* rho_u4) {
+    if (!f19 || !out19) return fail(nullptr, LBM_ERR_INVALID, "lbm_host_collide_cell: null argument");
+    const Moments m = moments_of(f19);
+    collide_cell(f19, m, omega_shear, omega_bulk, out19);
+    if (rho_u4) { rho_u4[0] = m.rho; rho_u4[1] = m.ux; rho_u4[2] = m.uy; rho_u4[3] = m.uz; }
+    return LBM_OK;
+}
+
 // ---- z-slab API ---------------------------------------------------------------------------
 static inline size_t halo_tail_floats(const lbm_ctx* c) { return (size_t)((c->g.H + 2 + 31) / 32 * 32); }
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "lbm_timer_end": ([_ctx], C.c_int),
     "lbm_last_error": ([_ctx], C.c_char_p),
     "lbm_abi_version": ([], C.c_int),
+    "lbm_host_voxelize_obj": ([C.c_char_p, C.c_int, C.c_int, C.c_int, _up, C.c_size_t, _fp], C.c_int),
+    "lbm_host_collide_cell": ([_fp, C.c_float, C.c_float, _fp, _fp], C.c_int),
     "lbm_halo_message_floats": ([_ctx, C.POINTER(C.c_size_t)], C.c_int),
     "lbm_halo_pack": ([_ctx, C.c_int, C.c_void_p], C.c_int),
     "lbm_halo_unpack": ([_ctx, C.c_int, C.c_void_p], C.c_int),
@@ -232,3 +234,22 @@ class Solver:
     def timer_end(self):
         self._chk(self._lib.lbm_timer_end(self._ctx))
         return self.stats()["last_timed_ms"]
+
+
+def host_voxelize_obj(path, W, H, D):
+    """Product voxeliser (host stage of load_mesh); returns (mask u8[n], scale, rc)."""
+    L = load_library()
+    mask = np.zeros(W * H * D, np.uint8)
+    sc = C.c_float(0)
+    rc = L.lbm_host_voxelize_obj(os.fsencode(path), W, H, D, _u(mask), mask.size, C.byref(sc))
+    return mask, sc.value, rc
+
+
+def host_collide_cell(f19, omega_shear, omega_bulk):
+    L = load_library()
+    f = np.ascontiguousarray(f19, np.float32)
+    out = np.zeros(19, np.float32)
+    ru = np.zeros(4, np.float32)
+    rc = L.lbm_host_collide_cell(_f(f), omega_shear, omega_bulk, _f(out), _f(ru))
+    assert rc == 0
+    return out, ru

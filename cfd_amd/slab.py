@@ -1,0 +1,243 @@
+"""z-slab decomposition of the D3Q19 path across the GPUs of one node.
+
+The reference is single-GPU (no NCCL/MPI call sites), so this layer has no counterpart there; it
+keeps the reference's arithmetic per cell, which makes an N-slab run bit-identical to the 1-GPU
+run.  One process per GPU; the halo messages travel by RCCL send/recv through torch.distributed
+(backend "nccl" is RCCL on ROCm), overlapped with the interior update:
+
+    boundary layers -> pack 2 messages -> isend/irecv (RCCL stream)  ||  interior layers
+    -> wait -> unpack into ghost layers -> A/B swap
+
+The engine (HIP context, or an oracle-backed stand-in in the CPU tests) and the transport (RCCL
+through torch.distributed, gloo in CPU tests, or a local copy between slabs that live in one
+process) are both pluggable; the schedule and the neighbour topology live here.
+"""
+import numpy as np
+import torch
+
+from . import lbm
+
+SIDE_BOTTOM, SIDE_TOP = 0, 1
+
+
+def slab_range(depth_global, world, rank):
+    """Even split of [0, depth_global) into `world` contiguous slabs; the first `rem` get one more."""
+    base, rem = divmod(depth_global, world)
+    z0 = rank * base + min(rank, rem)
+    return z0, base + (1 if rank < rem else 0)
+
+
+def neighbours(preset, world, rank):
+    """(down, up) ranks or None.  The wind-tunnel preset exchanges around a ring because the
+    reference's unchecked outlet index wraps from the last z layer to the first (quirk Q2,
+    lbm_solver.cu:292-296); the cavity preset is an open chain."""
+    if world == 1:
+        return (0, 0) if preset == lbm.PRESET_WIND_TUNNEL else (None, None)
+    if preset == lbm.PRESET_WIND_TUNNEL:
+        return (rank - 1) % world, (rank + 1) % world
+    return (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
+
+
+class HipSlabEngine:
+    """One HIP context owning global layers [z0, z0+D)."""
+
+    def __init__(self, W, H, depth_global, z0, D, preset, device=-1, stream=None):
+        self.solver = lbm.Solver(W, H, D, preset=preset, device=device, z0=z0,
+                                 depth_global=depth_global, stream=stream)
+        self._lib = self.solver._lib
+        self._ctx = self.solver._ctx
+        self.W, self.H, self.D, self.z0 = W, H, D, z0
+        self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+
+    def message_floats(self):
+        import ctypes as C
+        n = C.c_size_t(0)
+        self.solver._chk(self._lib.lbm_halo_message_floats(self._ctx, C.byref(n)))
+        return n.value
+
+    def new_message(self):
+        return torch.zeros(self.message_floats(), dtype=torch.float32, device=self.device)
+
+    def new_mask_layer(self):
+        return torch.zeros(self.W * self.H, dtype=torch.uint8, device=self.device)
+
+    def halo_pack(self, side, msg):
+        self.solver._chk(self._lib.lbm_halo_pack(self._ctx, side, msg.data_ptr()))
+
+    def halo_unpack(self, side, msg):
+        self.solver._chk(self._lib.lbm_halo_unpack(self._ctx, side, msg.data_ptr()))
+
+    def get_mask_layer(self, side):
+        import ctypes as C
+        a = np.empty(self.W * self.H, np.uint8)
+        self.solver._chk(self._lib.lbm_halo_get_mask_layer(
+            self._ctx, side, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size))
+        return a
+
+    def set_mask_ghost(self, side, layer):
+        import ctypes as C
+        a = np.ascontiguousarray(layer, np.uint8)
+        self.solver._chk(self._lib.lbm_halo_set_mask_ghost(
+            self._ctx, side, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size))
+
+    def step_boundary(self):
+        self.solver._chk(self._lib.lbm_step_boundary_layers(self._ctx))
+
+    def step_interior(self):
+        self.solver._chk(self._lib.lbm_step_interior_layers(self._ctx))
+
+    def step_finish(self):
+        self.solver._chk(self._lib.lbm_step_finish(self._ctx))
+
+
+class TorchP2P:
+    """Halo transport over torch.distributed point-to-point ops (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+
+    def exchange(self, items):
+        """items: list of (send_tensor, dst_rank, recv_tensor, src_rank); entries may have None
+        ranks.  Sends are issued in list order and so are receives, so two messages between the
+        same pair of ranks (2-rank ring) match up in order.  Returns a handle for wait()."""
+        dist = self.dist
+        ops = []
+        for send, dst, _, _ in items:
+            if dst is not None:
+                ops.append(dist.P2POp(dist.isend, send, dst, self.group))
+        for _, _, recv, src in items:
+            if src is not None:
+                ops.append(dist.P2POp(dist.irecv, recv, src, self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def wait(handle):
+        for w in handle:
+            w.wait()
+
+
+class SlabSolver:
+    """One rank's share of a W x H x depth_global domain.  Mirrors lbm_solver's surface for the
+    calls that make sense per slab (init, step, set_solid with the slab's own layers, read-back)."""
+
+    def __init__(self, engine, preset, world, rank, transport):
+        self.e = engine
+        self.preset, self.world, self.rank = preset, world, rank
+        self.t = transport
+        self.down, self.up = neighbours(preset, world, rank)
+        self.send = [engine.new_message(), engine.new_message()]
+        self.recv = [engine.new_message(), engine.new_message()]
+
+    # message leaving through our TOP face goes to `up` and lands on its BOTTOM ghost, and vice versa
+    def _items(self, send, recv):
+        return [(send[SIDE_TOP], self.up, recv[SIDE_BOTTOM], self.down),
+                (send[SIDE_BOTTOM], self.down, recv[SIDE_TOP], self.up)]
+
+    def exchange_mask(self):
+        """Static ghost layers of the solid mask; call after the mask changed on any rank."""
+        e = self.e
+        send = [None, None]
+        recv = [e.new_mask_layer(), e.new_mask_layer()]
+        for side in (SIDE_BOTTOM, SIDE_TOP):
+            send[side] = torch.from_numpy(e.get_mask_layer(side)).to(recv[0].device)
+        # the wrap link of the ring carries no mask: the end walls are tested before any solid
+        down = self.down if self.rank > 0 else None
+        up = self.up if self.rank < self.world - 1 else None
+        items = [(send[SIDE_TOP], up, recv[SIDE_BOTTOM], down),
+                 (send[SIDE_BOTTOM], down, recv[SIDE_TOP], up)]
+        self.t.wait(self.t.exchange(items))
+        if down is not None:
+            e.set_mask_ghost(SIDE_BOTTOM, recv[SIDE_BOTTOM].cpu().numpy())
+        if up is not None:
+            e.set_mask_ghost(SIDE_TOP, recv[SIDE_TOP].cpu().numpy())
+
+    def exchange_populations(self):
+        """Fill the ghost layers from the current state (after init / set_populations)."""
+        e = self.e
+        e.halo_pack(SIDE_BOTTOM, self.send[SIDE_BOTTOM])
+        e.halo_pack(SIDE_TOP, self.send[SIDE_TOP])
+        self.t.wait(self.t.exchange(self._items(self.send, self.recv)))
+        if self.down is not None:
+            e.halo_unpack(SIDE_BOTTOM, self.recv[SIDE_BOTTOM])
+        if self.up is not None:
+            e.halo_unpack(SIDE_TOP, self.recv[SIDE_TOP])
+
+    def step(self, nsteps=1):
+        e = self.e
+        for _ in range(nsteps):
+            e.step_boundary()
+            e.halo_pack(SIDE_BOTTOM, self.send[SIDE_BOTTOM])
+            e.halo_pack(SIDE_TOP, self.send[SIDE_TOP])
+            h = self.t.exchange(self._items(self.send, self.recv))   # travels while ...
+            e.step_interior()                                        # ... the interior updates
+            self.t.wait(h)
+            if self.down is not None:
+                e.halo_unpack(SIDE_BOTTOM, self.recv[SIDE_BOTTOM])
+            if self.up is not None:
+                e.halo_unpack(SIDE_TOP, self.recv[SIDE_TOP])
+            e.step_finish()
+
+
+class LocalSlabCluster:
+    """All slabs of a domain inside ONE process (one device, or CPU engines in tests): same
+    schedule and message routing as SlabSolver/TorchP2P, with tensor copies as the transport.
+    Used to check on a single GPU that an N-slab run equals the undecomposed run bit for bit."""
+
+    def __init__(self, engines, preset):
+        self.engines = engines
+        self.preset = preset
+        self.world = len(engines)
+        self.send = [[e.new_message(), e.new_message()] for e in engines]
+        self.recv = [[e.new_message(), e.new_message()] for e in engines]
+
+    def _route(self):
+        for r in range(self.world):
+            down, up = neighbours(self.preset, self.world, r)
+            if up is not None:
+                self.recv[up][SIDE_BOTTOM].copy_(self.send[r][SIDE_TOP])
+            if down is not None:
+                self.recv[down][SIDE_TOP].copy_(self.send[r][SIDE_BOTTOM])
+
+    def _unpack_all(self):
+        for r, e in enumerate(self.engines):
+            down, up = neighbours(self.preset, self.world, r)
+            if down is not None:
+                e.halo_unpack(SIDE_BOTTOM, self.recv[r][SIDE_BOTTOM])
+            if up is not None:
+                e.halo_unpack(SIDE_TOP, self.recv[r][SIDE_TOP])
+
+    def exchange_mask(self):
+        layers = [[e.get_mask_layer(SIDE_BOTTOM), e.get_mask_layer(SIDE_TOP)] for e in self.engines]
+        for r, e in enumerate(self.engines):
+            if r > 0:
+                e.set_mask_ghost(SIDE_BOTTOM, layers[r - 1][SIDE_TOP])
+            if r < self.world - 1:
+                e.set_mask_ghost(SIDE_TOP, layers[r + 1][SIDE_BOTTOM])
+
+    def exchange_populations(self):
+        for r, e in enumerate(self.engines):
+            e.halo_pack(SIDE_BOTTOM, self.send[r][SIDE_BOTTOM])
+            e.halo_pack(SIDE_TOP, self.send[r][SIDE_TOP])
+        self._sync()
+        self._route()
+        self._unpack_all()
+
+    def _sync(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            for r, e in enumerate(self.engines):
+                e.step_boundary()
+                e.halo_pack(SIDE_BOTTOM, self.send[r][SIDE_BOTTOM])
+                e.halo_pack(SIDE_TOP, self.send[r][SIDE_TOP])
+            for e in self.engines:
+                e.step_interior()
+            self._sync()
+            self._route()
+            self._unpack_all()
+            for e in self.engines:
+                e.step_finish()

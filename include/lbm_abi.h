@@ -138,6 +138,19 @@ int lbm_timer_end(lbm_ctx* ctx);   /* synchronises the stream and fills last_tim
 const char* lbm_last_error(lbm_ctx* ctx); /* ctx may be NULL: error of the last failed create */
 int lbm_abi_version(void);
 
+/* ---- host-only entry points: no device is touched --------------------------------------
+ * The voxelisation stage of lbm_solver::load_mesh alone (lbm_solver.cu:526-553 +
+ * mesh_voxelizer.cpp:146-216): writes the reference's uint8 mask (255 = solid, floor included)
+ * for a width x height x depth grid into `mask` (n = W*H*D bytes) and the auto-scale into
+ * *scale_out.  The reference runs this stage on the host too. */
+int lbm_host_voxelize_obj(const char* obj_path, int width, int height, int depth,
+                          uint8_t* mask, size_t n, float* scale_out);
+/* One cell of lbm_solver.cu:320-401 evaluated on the host with the very inline functions the
+ * kernels use (cfd_amd/csrc/d3q19.h): moments of f19, then the collision.  Diagnostic used to
+ * prove, without a GPU, that the folded arithmetic equals the reference's literal loops. */
+int lbm_host_collide_cell(const float* f19, float omega_shear, float omega_bulk,
+                          float* out19, float* rho_u4);
+
 /* ---- z-slab halo exchange (multi-GPU; the reference is single-GPU) ----
  * A context created with lbm_opts.depth_global > 0 is one z-slab of a taller domain.  After each
  * step it sends the five populations that cross its top face (k = 5,11,14,15,18) from its top

@@ -121,6 +121,25 @@ static inline void collide_cell(const float* f, float rho, float ux, float uy, f
     }
 }
 
+/* One cell, literal form: moments (lbm_solver.cu:320-334) then collision.  For host-logic tests. */
+void orc_collide_cell(const float* f, float omega_shear, float omega_bulk, float* out, float* rho_u4) {
+    float rho = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+    for (int k = 0; k < Q; k++) {
+        rho += f[k];
+        ux += f[k] * CX[k];
+        uy += f[k] * CY[k];
+        uz += f[k] * CZ[k];
+    }
+    if (rho > 1e-9f) {
+        float inv_rho = 1.0f / rho;
+        ux *= inv_rho; uy *= inv_rho; uz *= inv_rho;
+    } else {
+        rho = 1.0f;
+    }
+    rho_u4[0] = rho; rho_u4[1] = ux; rho_u4[2] = uy; rho_u4[3] = uz;
+    collide_cell(f, rho, ux, uy, uz, omega_shear, omega_bulk, out);
+}
+
 /* Lid term of the cavity preset (own extension): moving-wall half-way bounce-back with rho_w=1.
  * The product kernel uses the same single-rounded expression. */
 static inline float lid_term(int k, float U) { return (6.0f * W19[k]) * ((float)CX[k] * U); }

@@ -47,6 +47,7 @@ def lib():
         L.orc_add_solid_rect.argtypes = [up] + [C.c_int] * 9
         L.orc_load_mesh.argtypes = [C.c_char_p, up, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.orc_load_mesh.restype = C.c_int
+        L.orc_collide_cell.argtypes = [fp, C.c_float, C.c_float, fp, fp]
         L.orc_fnv1a64.argtypes = [up, C.c_size_t]
         L.orc_fnv1a64.restype = C.c_ulonglong
         L.orc_mesh_new.restype = C.c_void_p
@@ -177,3 +178,18 @@ def load_obj_triangles(path):
         return rc, tris, b
     finally:
         L.orc_mesh_free(m)
+
+
+def collide_cell(f19, omega_shear, omega_bulk):
+    f = np.ascontiguousarray(f19, np.float32)
+    out = np.zeros(Q, np.float32)
+    ru = np.zeros(4, np.float32)
+    lib().orc_collide_cell(_fp(f), omega_shear, omega_bulk, _fp(out), _fp(ru))
+    return out, ru
+
+
+def voxelize_obj(path, W, H, D, floor_plane=True):
+    mask = np.zeros(W * H * D, np.uint8)
+    sc = C.c_float(0)
+    rc = lib().orc_load_mesh(os.fsencode(path), _up(mask), W, H, D, int(bool(floor_plane)), C.byref(sc))
+    return mask, sc.value, rc
