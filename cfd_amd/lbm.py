@@ -91,6 +91,13 @@ def load_library(path=None):
             raise FileNotFoundError(
                 f"{p} is missing: build it with `make -C cfd_amd/csrc` (or __graft_entry__.build()); "
                 "the hot path has no CPU fallback")
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Two HIP runtimes in one
+        # process do not work ("No HIP GPUs are available"), so when torch is installed let it
+        # load its runtime FIRST; our NEEDED libamdhip64.so.7 then binds to that same copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(p)
         for name, (args, res) in SIGNATURES.items():
             fn = getattr(lib, name)

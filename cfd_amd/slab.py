@@ -222,6 +222,7 @@ class LocalSlabCluster:
             e.halo_pack(SIDE_TOP, self.send[r][SIDE_TOP])
         self._sync()
         self._route()
+        self._sync()
         self._unpack_all()
 
     def _sync(self):
@@ -238,6 +239,7 @@ class LocalSlabCluster:
                 e.step_interior()
             self._sync()
             self._route()
+            self._sync()
             self._unpack_all()
             for e in self.engines:
                 e.step_finish()
