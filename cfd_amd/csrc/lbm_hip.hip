@@ -63,6 +63,17 @@ __device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long*
     return (w >> (x & 63)) & 1ull;
 }
 
+// population load / store with an explicit cache policy (TUNE bit 0: nt loads, bit 1: sc1 stores)
+template <int TUNE>
+__device__ __forceinline__ float ldf(const float* p) {
+    return (TUNE & 1) ? __builtin_nontemporal_load(p) : *p;
+}
+template <int TUNE>
+__device__ __forceinline__ void stf(float* p, float v) {
+    if (TUNE & 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+    else __builtin_nontemporal_store(v, p);
+}
+
 // Which branch of the reference chain (lbm_solver.cu:283-318) feeds direction K of the fluid cell
 // (x, y, zl).  Single source of truth for the step kernel, the moment kernel and
 // lbm_read_classification.
@@ -128,33 +139,34 @@ __device__ __forceinline__ float gather_general(const Geo& g, const float* __res
 
 // interior tile: rows y-1..y+1 and layers z-1..z+1 exist, no solid cell within reach; only the
 // x ends of the row need care.
-template <int PRESET, int K>
+template <int PRESET, int K, int TUNE>
 __device__ __forceinline__ float gather_fast(const Geo& g, const float* __restrict__ fin,
                                              int x, int y, int zl, long long own, float inlet_e) {
     constexpr int cx = CX[K];
     const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
                        (long long)(y - CY[K]) * g.Wp;
-    if (cx == 0) return row[x];
+    if (cx == 0) return ldf<TUNE>(row + x);
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
         if (cx == 1) {
-            const float v = row[x - 1];  // x = 0 reads the pad/previous row: in bounds, discarded
+            const float v = ldf<TUNE>(row + x - 1);  // x = 0 reads the pad/previous row: in bounds, discarded
             return x == 0 ? weight(K) * inlet_e : v;
         }
         const int xs = x + 1 < g.W ? x + 1 : g.W - 1;  // outlet: copy from x = W-1 (ny, nz in range here)
-        return row[xs];
+        return ldf<TUNE>(row + xs);
     } else {
         const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
         if (wall) return fin[(long long)INV[K] * g.plane + own];
-        return row[x - cx];
+        return ldf<TUNE>(row + x - cx);
     }
 }
 
 template <int PRESET, int K>
 struct GatherAll {
+    template <int TUNE>
     static __device__ __forceinline__ void fast(const Geo& g, const float* __restrict__ fin, int x, int y,
                                                 int zl, long long own, float inlet_e, float* f) {
-        GatherAll<PRESET, K - 1>::fast(g, fin, x, y, zl, own, inlet_e, f);
-        f[K] = gather_fast<PRESET, K>(g, fin, x, y, zl, own, inlet_e);
+        GatherAll<PRESET, K - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
+        f[K] = gather_fast<PRESET, K, TUNE>(g, fin, x, y, zl, own, inlet_e);
     }
     static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin,
                                                    const unsigned long long* __restrict__ mask, int x, int y,
@@ -170,6 +182,7 @@ struct GatherAll {
 };
 template <int PRESET>
 struct GatherAll<PRESET, -1> {
+    template <int TUNE>
     static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
     static __device__ __forceinline__ void general(const Geo&, const float*, const unsigned long long*, int, int,
                                                    int, long long, float, float, float*) {}
@@ -196,15 +209,17 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
 // the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
 // MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
 // ------------------------------------------------------------------------------------------
-template <int PRESET, int MODE>
+template <int PRESET, int MODE, int TUNE>
 __global__ __launch_bounds__(256) void k_stream_collide(
     const float* __restrict__ fin, float* __restrict__ fout,
     const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
     float* __restrict__ rho_out, float4* __restrict__ u_out,
-    Geo g, Params p, int zl_begin, int segsx_log2) {
+    Geo g, Params p, int zl_begin, int segsx_log2, int zrev) {
     const TileId t = tile_of_wave(segsx_log2);
     const int y = t.y;
-    const int zl = zl_begin + blockIdx.z;  // local layer incl. ghost offset (owned: 1..D)
+    // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
+    // starts on the layers the previous step wrote last (still in the Infinity Cache)
+    const int zl = zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     float f[Q];
 
     if (flag == 0) {
-        GatherAll<PRESET, Q - 1>::fast(g, fin, x, y, zl, own, inlet_e, f);
+        GatherAll<PRESET, Q - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
     } else {
         if (solid_at(g, mask, x, y, zl)) {
             // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
     float* dst = fout + own;
 #pragma unroll
-    for (int k = 0; k < Q; k++) __builtin_nontemporal_store(o[k], dst + (long long)k * g.plane);
+    for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -498,7 +513,9 @@ struct lbm_ctx {
     FieldState fields = FIELDS_INIT;
     bool curl_valid = false;
     int segsx_log2 = 0;
-    int split_phase = 0;       // 0 idle, 1 boundary layers issued, 2 interior issued
+    int split_phase = 0;
+    int tune = 0;              // bit 0 nt loads, bit 1 sc1 stores, bit 2 alternate z direction per step
+    int zrev = 0;       // 0 idle, 1 boundary layers issued, 2 interior issued
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t steps = 0, steps_at_begin = 0;
     double last_ms = 0.0;
@@ -565,12 +582,21 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     if (nlayers <= 0) return LBM_OK;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
-    if (c->preset == LBM_PRESET_CAVITY)
-        hipLaunchKernelGGL((k_stream_collide<LBM_PRESET_CAVITY, MODE>), grid, dim3(256), 0, c->stream, fin, fout,
-                           c->mask, c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2);
-    else
-        hipLaunchKernelGGL((k_stream_collide<LBM_PRESET_WIND_TUNNEL_REF, MODE>), grid, dim3(256), 0, c->stream, fin,
-                           fout, c->mask, c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2);
+    const int zrev = (MODE == 0 && (c->tune & 4)) ? c->zrev : 0;
+#define LBM_LAUNCH(PRESET, TUNE)                                                                              \
+    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), 0, c->stream, fin, fout, c->mask, \
+                       c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev)
+#define LBM_LAUNCH_T(PRESET)                          \
+    switch (c->tune & 3) {                            \
+        case 0: LBM_LAUNCH(PRESET, 0); break;         \
+        case 1: LBM_LAUNCH(PRESET, 1); break;         \
+        case 2: LBM_LAUNCH(PRESET, 2); break;         \
+        default: LBM_LAUNCH(PRESET, 3); break;        \
+    }
+    if (c->preset == LBM_PRESET_CAVITY) { LBM_LAUNCH_T(LBM_PRESET_CAVITY) }
+    else { LBM_LAUNCH_T(LBM_PRESET_WIND_TUNNEL_REF) }
+#undef LBM_LAUNCH_T
+#undef LBM_LAUNCH
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
 }
@@ -640,10 +666,14 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     g.Wm = (width + 63) / 64;
     g.Wt = g.Wm;
     g.layer = (long long)height * g.Wp;
-    long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 4352) / 4;  // 4 KiB + 256 B
+    long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 3072) / 4;  // measured best of a 0..1 MiB sweep
     skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
     g.plane = (long long)(depth + 2) * g.layer + skew_floats;
     c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
+    // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
+    // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
+    c->tune = 7;
+    if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
     c->pop_bytes = (size_t)Q * g.plane * sizeof(float);
 
     auto cleanup = [&](int code) {
@@ -781,6 +811,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D);
         if (rc) return rc;
         c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
+        c->zrev ^= 1;
     }
     c->p_last = c->p;
     c->steps += (uint64_t)nsteps;

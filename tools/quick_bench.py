@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfd_amd import lbm
 
 def run(W, H, D, preset, steps=100, warm=20, skew=-1, label=""):
+    label = label or ("tune=" + os.environ.get("LBM_TUNE", "0"))
     s = lbm.Solver(W, H, D, preset=preset, plane_skew_bytes=skew)
     s.init(); s.step(warm); s.sync()
     best = 1e9
