@@ -507,6 +507,7 @@ struct lbm_ctx {
     float* rho = nullptr;
     float4* u = nullptr;
     float* curl = nullptr;
+    unsigned char* solid_dense = nullptr;
     Params p{0.08f, 1.98f, 1.90f};  // lbm_solver.cuh:11-13
     Params p_last{0.08f, 1.98f, 1.90f};
     bool mask_dirty = true;    // tile flags / solid sync pending
@@ -712,7 +713,7 @@ int lbm_destroy(lbm_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->f[0]); hipFree(c->f[1]); hipFree(c->mask); hipFree(c->flags);
-    hipFree(c->rho); hipFree(c->u); hipFree(c->curl);
+    hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -942,10 +943,18 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     return LBM_OK;
 }
 
-int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl) {
+int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, uint8_t** d_solid) {
     NEED(c);
     int rc = lbm_compute_curl(c);
     if (rc) return rc;
+    if (d_solid) {  // dense copy of the bit-packed mask in the reference's wire format
+        const long long n = cells(c);
+        if (!c->solid_dense) HIPCHK(c, hipMalloc(&c->solid_dense, (size_t)n));
+        hipLaunchKernelGGL(k_unpack_mask, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->mask, c->solid_dense, c->g);
+        HIPCHK(c, hipGetLastError());
+        *d_solid = c->solid_dense;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (d_rho) *d_rho = c->rho;
     if (d_u) *d_u = reinterpret_cast<float*>(c->u);
     if (d_curl) *d_curl = c->curl;

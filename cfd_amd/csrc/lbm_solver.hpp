@@ -1,0 +1,169 @@
+// lbm_solver.hpp -- the reference's solver interface on top of the C ABI (include/lbm_abi.h).
+//
+// Drop-in for Engine/src/Physics/lbm_solver.cuh:9-51 in a headless build of the engine: same
+// class name, member names, argument meaning and error behaviour, so Engine/src/main.cpp:17-28,36
+// compiles against it unchanged (minus the Vulkan interop calls).  Header-only; link liblbm_hip.so.
+//
+//   reference                                   here
+//   ---------------------------------------     ------------------------------------------------
+//   struct settings (lbm_solver.cuh:9-15)        same fields and defaults; read at every step()
+//   cuda_math::vec4 (cuda_math.cuh:37-55)        same 16-byte {x,y,z,w}
+//   cuda_buffer<T> (cuda_buffer.cuh:18-122)      hip_buffer<T>: copy_to_host / get_data views of
+//                                                the solver's fields in the reference wire format
+//   CUDA_CHECK -> log + exit (cuda_buffer.cuh:9) LBM_CHECK -> log + std::exit(EXIT_FAILURE)
+//   register_external_* (lbm_solver.cu:558-717)  throw std::runtime_error (CUDA-Vulkan interop is
+//                                                out of scope)
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lbm_abi.h"
+
+struct settings {
+    float tau = 0.55f;  // dead in the reference's live kernel; kept for source compatibility
+    float inlet_velocity = 0.08f;
+    float omega_shear = 1.98f;
+    float omega_bulk = 1.90f;
+};
+
+namespace cuda_math {
+struct vec4 {
+    float x, y, z, w;
+};
+}  // namespace cuda_math
+
+#define LBM_CHECK(ctx, call)                                                                  \
+    do {                                                                                      \
+        int rc_ = (call);                                                                     \
+        if (rc_ != LBM_OK) {                                                                  \
+            std::fprintf(stderr, "[error] LBM error %d: %s at %s:%d\n", rc_, lbm_last_error(ctx), \
+                         __FILE__, __LINE__);                                                 \
+            std::exit(EXIT_FAILURE);                                                          \
+        }                                                                                     \
+    } while (0)
+
+// View of one solver field with the call surface of cuda_buffer<T> that the engine uses.
+template <typename T>
+class hip_buffer {
+   public:
+    enum class field { density, velocity, solid, curl };
+    hip_buffer() = default;
+    hip_buffer(lbm_ctx* ctx, field f, size_t size) : m_ctx(ctx), m_field(f), m_size(size) {}
+    hip_buffer(const hip_buffer&) = delete;  // reference quirk Q8 (shallow copy) not reproduced
+    hip_buffer& operator=(const hip_buffer&) = delete;
+    hip_buffer(hip_buffer&&) = default;
+    hip_buffer& operator=(hip_buffer&&) = default;
+
+    // cuda_buffer.cuh:79-84: blocking D2H copy of `size` elements, silently skipped if size > m_size
+    void copy_to_host(T* host_data, size_t size) {
+        if (!m_ctx || size > m_size) return;
+        if (size == m_size) {
+            read_all(host_data);
+        } else {
+            std::vector<T> tmp(m_size);
+            read_all(tmp.data());
+            std::memcpy(host_data, tmp.data(), size * sizeof(T));
+        }
+    }
+    // device pointer in the reference wire format, up to date and synchronised
+    T* get_data() {
+        if (!m_ctx) {
+            std::fprintf(stderr, "[error] Trying to access null device pointer!\n");
+            return nullptr;
+        }
+        float *rho = nullptr, *u = nullptr, *curl = nullptr;
+        uint8_t* solid = nullptr;
+        LBM_CHECK(m_ctx, lbm_device_fields(m_ctx, &rho, &u, &curl, m_field == field::solid ? &solid : nullptr));
+        switch (m_field) {
+            case field::density: return reinterpret_cast<T*>(rho);
+            case field::velocity: return reinterpret_cast<T*>(u);
+            case field::curl: return reinterpret_cast<T*>(curl);
+            default: return reinterpret_cast<T*>(solid);
+        }
+    }
+    size_t size() const { return m_size; }
+
+   private:
+    void read_all(T* dst) {
+        switch (m_field) {
+            case field::density: LBM_CHECK(m_ctx, lbm_read_density(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
+            case field::velocity: LBM_CHECK(m_ctx, lbm_read_velocity(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
+            case field::curl: LBM_CHECK(m_ctx, lbm_read_curl(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
+            case field::solid: LBM_CHECK(m_ctx, lbm_read_solid_u8(m_ctx, reinterpret_cast<uint8_t*>(dst), m_size)); break;
+        }
+    }
+    lbm_ctx* m_ctx = nullptr;
+    field m_field = field::density;
+    size_t m_size = 0;
+};
+
+class lbm_solver {
+   public:
+    lbm_solver(int width, int height, int depth, int preset = LBM_PRESET_WIND_TUNNEL_REF)
+        : m_width(width), m_height(height), m_depth(depth) {
+        lbm_opts o{};
+        o.struct_size = sizeof(lbm_opts);
+        o.device = -1;
+        o.preset = preset;
+        o.plane_skew_bytes = -1;
+        LBM_CHECK(nullptr, lbm_create(&m_ctx, width, height, depth, &o));
+        const size_t n = static_cast<size_t>(width) * height * depth;
+        d_rho = hip_buffer<float>(m_ctx, hip_buffer<float>::field::density, n);
+        d_u = hip_buffer<cuda_math::vec4>(m_ctx, hip_buffer<cuda_math::vec4>::field::velocity, n);
+        d_solid = hip_buffer<unsigned char>(m_ctx, hip_buffer<unsigned char>::field::solid, n);
+        d_curl = hip_buffer<float>(m_ctx, hip_buffer<float>::field::curl, n);
+    }
+    ~lbm_solver() { lbm_destroy(m_ctx); }
+    lbm_solver(const lbm_solver&) = delete;
+    lbm_solver& operator=(const lbm_solver&) = delete;
+
+    void init() { LBM_CHECK(m_ctx, lbm_init(m_ctx)); }
+    void step() {  // lbm_solver.cu:477-494: settings are read at every launch
+        LBM_CHECK(m_ctx, lbm_set_params(m_ctx, m_settings.inlet_velocity, m_settings.omega_shear, m_settings.omega_bulk));
+        LBM_CHECK(m_ctx, lbm_step(m_ctx, 1));
+    }
+    void reset() { init(); }
+    void compute_curl() { LBM_CHECK(m_ctx, lbm_compute_curl(m_ctx)); }
+
+    struct Rect {
+        int x, y, z, w, h, d;
+    };
+    void add_solid(const Rect& r) { LBM_CHECK(m_ctx, lbm_add_solid_rect(m_ctx, r.x, r.y, r.z, r.w, r.h, r.d)); }
+
+    void register_external_density(int, size_t) { throw std::runtime_error("Failed to import external memory: Vulkan interop is not part of the HIP solver"); }
+    void register_external_velocity(int, size_t) { throw std::runtime_error("Failed to import external velocity memory: Vulkan interop is not part of the HIP solver"); }
+    void register_external_curl(int, size_t) { throw std::runtime_error("Failed to import external curl memory: Vulkan interop is not part of the HIP solver"); }
+    void register_external_solid(int, size_t) { throw std::runtime_error("Failed to import external solid memory: Vulkan interop is not part of the HIP solver"); }
+
+    void load_mesh(const std::string& path) {  // lbm_solver.cu:521-556: a missing mesh only logs
+        const int rc = lbm_load_mesh(m_ctx, path.c_str());
+        if (rc == LBM_ERR_IO) std::fprintf(stderr, "[error] Failed to load mesh: %s\n", path.c_str());
+        else LBM_CHECK(m_ctx, rc);
+    }
+
+    hip_buffer<float>& get_density() { return d_rho; }
+    hip_buffer<cuda_math::vec4>& get_velocity() { return d_u; }
+    hip_buffer<unsigned char>& get_solid_mask() { return d_solid; }
+    hip_buffer<float>& get_curl() { return d_curl; }
+
+    int get_width() const { return m_width; }
+    int get_height() const { return m_height; }
+    int get_depth() const { return m_depth; }
+    settings& get_settings() { return m_settings; }
+
+    lbm_ctx* native_handle() { return m_ctx; }
+    void sync() { LBM_CHECK(m_ctx, lbm_sync(m_ctx)); }
+
+   private:
+    int m_width, m_height, m_depth;
+    settings m_settings;
+    lbm_ctx* m_ctx = nullptr;
+    hip_buffer<float> d_rho;
+    hip_buffer<cuda_math::vec4> d_u;
+    hip_buffer<unsigned char> d_solid;
+    hip_buffer<float> d_curl;
+};

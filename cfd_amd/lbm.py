@@ -60,7 +60,7 @@ SIGNATURES = {
     "lbm_read_populations": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_write_populations": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_classification": ([_ctx, _up, C.c_size_t], C.c_int),
-    "lbm_device_fields": ([_ctx, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp)], C.c_int),
+    "lbm_device_fields": ([_ctx, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_up)], C.c_int),
     "lbm_get_dims": ([_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "lbm_get_stats": ([_ctx, C.POINTER(Stats)], C.c_int),
     "lbm_timer_begin": ([_ctx], C.c_int),

@@ -127,9 +127,11 @@ int lbm_write_populations(lbm_ctx* ctx, const float* f, size_t n_times_19);
  *  7 wall-BB (cavity), 8 lid-BB (cavity)}; 0 for every k of a solid cell. */
 int lbm_read_classification(lbm_ctx* ctx, uint8_t* cls, size_t n_times_19);
 
-/* Device pointers of the materialised fields in the reference wire formats, for consumers that
- * stay on the GPU (the reference hands d_u/d_solid to its renderer, lbm_solver.cuh:40-46). */
-int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_curl);
+/* Device pointers of the fields in the reference wire formats, brought up to date and
+ * synchronised, for consumers that stay on the GPU (the reference hands d_u/d_solid to its
+ * renderer: get_velocity()/get_solid_mask(), lbm_solver.cuh:40-46; renderer.cpp:1382-1389).
+ * Any output pointer may be NULL.  d_solid is a dense uint8 copy (0/255) of the packed mask. */
+int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_curl, uint8_t** d_solid);
 
 int lbm_get_dims(lbm_ctx* ctx, int* w, int* h, int* d);
 int lbm_get_stats(lbm_ctx* ctx, lbm_stats* out);

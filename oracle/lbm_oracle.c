@@ -219,6 +219,68 @@ void orc_step(const float* f_in, float* f_out, float* rho_out, float* u_out,
             }
 }
 
+/* ---- one step of a z-slab (test infrastructure for the multi-GPU protocol) -----------------
+ * The slab owns global layers [z0, z0+D) of a domain Dg deep and stores D+2 layers: local layer
+ * zl = 0 and zl = D+1 are ghost layers filled by the halo exchange (cfd_amd/slab.py).  Same chain
+ * as orc_step; wall tests use global z; the outlet's unchecked index (Q2) is followed in logical
+ * (plane, y, z) terms and a read that leaves the slab in z lands in the ghost layer, where the
+ * ring exchange deposits the values it needs.  Arrays: f[k][(D+2)][H][W], solid[(D+2)][H][W],
+ * rho[D][H][W], u[D][H][W][4].  Updates owned layers zl in [zl_begin, zl_end). */
+void orc_step_slab(const float* f_in, float* f_out, float* rho_out, float* u_out,
+                   const unsigned char* solid, int W, int H, int D, int Dg, int z0,
+                   float inlet_velocity, float omega_shear, float omega_bulk, int preset,
+                   int zl_begin, int zl_end) {
+    const long long layer = (long long)W * H;
+    const long long n = layer * (D + 2);
+#define SOFF(x, y, zl) ((long long)(zl) * layer + (long long)(y) * W + (x))
+    for (int zl = zl_begin; zl < zl_end; zl++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const long long idx = SOFF(x, y, zl);
+                const long long ridx = idx - layer;
+                const int zg = z0 + zl - 1;
+                if (solid[idx] > 0) {
+                    rho_out[ridx] = 0.0f;
+                    u_out[4 * ridx + 0] = u_out[4 * ridx + 1] = u_out[4 * ridx + 2] = u_out[4 * ridx + 3] = 0.0f;
+                    for (int k = 0; k < Q; k++) f_out[k * n + idx] = f_in[k * n + idx];
+                    continue;
+                }
+                float f[Q];
+                float rho = 0.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;
+                for (int k = 0; k < Q; k++) {
+                    int nx = x - CX[k], ny = y - CY[k], nzg = zg - CZ[k], nzl = zl - CZ[k];
+                    if (preset == PRESET_CAVITY) {
+                        if (ny >= H) f[k] = f_in[INV[k] * n + idx] + lid_term(k, inlet_velocity);
+                        else if (nx < 0 || nx >= W || ny < 0 || nzg < 0 || nzg >= Dg) f[k] = f_in[INV[k] * n + idx];
+                        else f[k] = (solid[SOFF(nx, ny, nzl)] > 0) ? f_in[INV[k] * n + idx] : f_in[k * n + SOFF(nx, ny, nzl)];
+                    } else if (nx < 0) {
+                        float usq = inlet_velocity * inlet_velocity + 0.0f * 0.0f + 0.0f * 0.0f;
+                        float cu = CX[k] * inlet_velocity + CY[k] * 0.0f + CZ[k] * 0.0f;
+                        f[k] = W19[k] * 1.0f * (1.0f + 3.0f * cu + 4.5f * cu * cu - 1.5f * usq);
+                    } else if (nx >= W) {
+                        int pl = k, qy = ny, qzg = nzg;
+                        if (qy < 0) { qy += H; qzg -= 1; } else if (qy >= H) { qy -= H; qzg += 1; }
+                        if (qzg < 0) pl -= 1; else if (qzg >= Dg) pl += 1;   /* layer stays in the ghost */
+                        f[k] = f_in[pl * n + SOFF(W - 1, qy, qzg - z0 + 1)];
+                    } else if (ny < 0) f[k] = f_in[INV[k] * n + idx];
+                    else if (ny >= H) f[k] = f_in[RFY[k] * n + idx];
+                    else if (nzg < 0 || nzg >= Dg) f[k] = f_in[RFZ[k] * n + idx];
+                    else f[k] = (solid[SOFF(nx, ny, nzl)] > 0) ? f_in[INV[k] * n + idx] : f_in[k * n + SOFF(nx, ny, nzl)];
+                    rho += f[k];
+                    ux += f[k] * CX[k];
+                    uy += f[k] * CY[k];
+                    uz += f[k] * CZ[k];
+                }
+                if (rho > 1e-9f) { float ir = 1.0f / rho; ux *= ir; uy *= ir; uz *= ir; } else rho = 1.0f;
+                rho_out[ridx] = rho;
+                u_out[4 * ridx + 0] = ux; u_out[4 * ridx + 1] = uy; u_out[4 * ridx + 2] = uz; u_out[4 * ridx + 3] = 0.0f;
+                float o[Q];
+                collide_cell(f, rho, ux, uy, uz, omega_shear, omega_bulk, o);
+                for (int k = 0; k < Q; k++) f_out[k * n + idx] = o[k];
+            }
+#undef SOFF
+}
+
 /* Convenience: N steps with A/B swap (lbm_solver.cu:477-494).  On return f_a holds the
  * current populations (an odd number of swaps is undone by a copy). */
 void orc_run(float* f_a, float* f_b, float* rho, float* u4, const unsigned char* solid,

@@ -47,6 +47,7 @@ def lib():
         L.orc_add_solid_rect.argtypes = [up] + [C.c_int] * 9
         L.orc_load_mesh.argtypes = [C.c_char_p, up, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.orc_load_mesh.restype = C.c_int
+        L.orc_step_slab.argtypes = [fp, fp, fp, fp, up] + [C.c_int] * 5 + [C.c_float] * 3 + [C.c_int] * 3
         L.orc_collide_cell.argtypes = [fp, C.c_float, C.c_float, fp, fp]
         L.orc_fnv1a64.argtypes = [up, C.c_size_t]
         L.orc_fnv1a64.restype = C.c_ulonglong

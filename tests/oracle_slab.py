@@ -1,0 +1,103 @@
+"""Oracle-backed slab engine for CPU tests of the multi-GPU protocol (cfd_amd/slab.py).
+
+Implements the engine interface that slab.SlabSolver / LocalSlabCluster drive (step split, halo
+pack/unpack with the documented message layout, static mask ghost layers) on top of
+oracle.orc_step_slab, with torch CPU tensors as messages so gloo can carry them.  TEST ONLY."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+UP5 = [5, 11, 14, 15, 18]
+DOWN5 = [6, 12, 13, 16, 17]
+
+
+class OracleSlabEngine:
+    def __init__(self, W, H, depth_global, z0, D, preset):
+        self.W, self.H, self.D, self.Dg, self.z0, self.preset = W, H, D, depth_global, z0, preset
+        self.layer = W * H
+        self.nl = self.layer * (D + 2)
+        w = O.tables()["w"]
+        self.f = [np.repeat(w, self.nl).astype(np.float32).reshape(19, D + 2, H, W).copy() for _ in range(2)]
+        self.cur = 0
+        self.solid = np.zeros((D + 2, H, W), np.uint8)
+        self.rho = np.ones(self.layer * D, np.float32)
+        self.u = np.zeros(4 * self.layer * D, np.float32)
+        self.params = (np.float32(0.08), np.float32(1.98), np.float32(1.90))
+        self.phase = 0
+
+    def set_solid(self, m):
+        self.solid[1:-1] = np.asarray(m, np.uint8).reshape(self.D, self.H, self.W)
+
+    def _run(self, zb, ze):
+        if ze <= zb:
+            return
+        fin, fout = self.f[self.cur], self.f[1 - self.cur]
+        O.lib().orc_step_slab(O._fp(fin), O._fp(fout), O._fp(self.rho), O._fp(self.u), O._up(self.solid),
+                              self.W, self.H, self.D, self.Dg, self.z0, *self.params, self.preset, zb, ze)
+
+    def step_boundary(self):
+        self._run(1, 2)
+        if self.D > 1:
+            self._run(self.D, self.D + 1)
+        self.phase = 1
+
+    def step_interior(self):
+        self._run(2, self.D)
+        self.phase = 2
+
+    def step_finish(self):
+        self.cur = 1 - self.cur
+        self.phase = 0
+
+    def _state(self):
+        return self.f[1 - self.cur] if self.phase else self.f[self.cur]
+
+    def message_floats(self):
+        return 5 * self.layer + self.H + 2
+
+    def new_message(self):
+        return torch.zeros(self.message_floats(), dtype=torch.float32)
+
+    def new_mask_layer(self):
+        return torch.zeros(self.layer, dtype=torch.uint8)
+
+    def halo_pack(self, side, msg):
+        f = self._state()
+        zl = self.D if side else 1
+        m = msg.numpy()
+        for j, k in enumerate(UP5 if side else DOWN5):
+            m[j * self.layer:(j + 1) * self.layer] = f[k, zl].reshape(-1)
+        t = m[5 * self.layer:]
+        t[:] = 0
+        if side:
+            t[0] = f[10, zl, self.H - 1, self.W - 1]
+            t[1] = f[9, zl, self.H - 1, self.W - 1]
+            t[2:] = f[13, zl, :, self.W - 1]
+        else:
+            t[0] = f[8, zl, 0, self.W - 1]
+            t[1] = f[9, zl, 0, self.W - 1]
+
+    def halo_unpack(self, side, msg):
+        f = self._state()
+        zl = self.D + 1 if side else 0
+        m = msg.numpy()
+        for j, k in enumerate(DOWN5 if side else UP5):
+            f[k, zl] = m[j * self.layer:(j + 1) * self.layer].reshape(self.H, self.W)
+        t = m[5 * self.layer:]
+        if side == 0:
+            f[10, zl, self.H - 1, self.W - 1] = t[0]
+            f[9, zl, self.H - 1, self.W - 1] = t[1]
+            f[13, zl, :, self.W - 1] = t[2:]
+        else:
+            f[8, zl, 0, self.W - 1] = t[0]
+            f[9, zl, 0, self.W - 1] = t[1]
+
+    def get_mask_layer(self, side):
+        return self.solid[self.D if side else 1].reshape(-1).copy()
+
+    def set_mask_ghost(self, side, layer):
+        self.solid[self.D + 1 if side else 0] = np.asarray(layer, np.uint8).reshape(self.H, self.W)
+
+    def populations(self):
+        return self.f[self.cur][:, 1:-1].reshape(19, -1).copy()

@@ -1,0 +1,30 @@
+"""The C++ `lbm_solver` mirror (cfd_amd/csrc/lbm_solver.hpp) and the headless driver, built by
+`make -C cfd_amd/csrc` (g++ against the C ABI), run on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import CUBE_OBJ, ROOT
+
+pytestmark = pytest.mark.gpu
+CSRC = os.path.join(ROOT, "cfd_amd", "csrc")
+
+
+def test_cpp_lbm_solver_tests():
+    exe = os.path.join(CSRC, "test_lbm_solver")
+    assert os.path.exists(exe), "build it with make -C cfd_amd/csrc"
+    r = subprocess.run([exe, CUBE_OBJ], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all C++ lbm_solver tests passed" in r.stdout
+
+
+def test_headless_driver_known_answer(tmp_path):
+    exe = os.path.join(CSRC, "lbm_headless")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, "--dims", "64", "64", "64", "--steps", "10", "--obj", CUBE_OBJ, "--dump", prefix],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "solid=9196" in r.stdout and "sum_rho=255103.576208234" in r.stdout, r.stdout
+    assert os.path.getsize(prefix + ".u.raw") == 64 ** 3 * 16
+    assert os.path.getsize(prefix + ".solid.raw") == 64 ** 3

@@ -1,0 +1,116 @@
+"""The z-slab halo protocol (cfd_amd/slab.py: neighbour topology, message routing, schedule) on
+CPU: oracle-backed slab engines, (a) inside one process via LocalSlabCluster and (b) as two real
+ranks over torch.distributed/gloo via SlabSolver + TorchP2P -- the same driver code bench.py runs
+over RCCL.  A decomposed run must equal the undecomposed oracle bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def reference_run(oracle, W, H, Dg, preset, steps, rects):
+    o = oracle.Solver(W, H, Dg, preset)
+    o.init()
+    for r in rects:
+        o.add_solid(*r)
+    mask = o.solid_mask()
+    o.step(steps)
+    return o, mask
+
+
+RECTS = [(8, 0, 2, 5, 6, 9), (20, 5, 5, 3, 3, 2)]
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("splits", [(12,), (6, 6), (5, 3, 4), (1, 10, 1)])
+def test_local_cluster_equals_single_domain(oracle, preset, splits):
+    from cfd_amd import slab
+    from oracle_slab import OracleSlabEngine
+    W, H, Dg, steps = 28, 10, 12, 7
+    o, mask = reference_run(oracle, W, H, Dg, preset, steps, RECTS)
+    engines, z0 = [], 0
+    for d in splits:
+        e = OracleSlabEngine(W, H, Dg, z0, d, preset)
+        e.set_solid(mask.reshape(Dg, H, W)[z0:z0 + d])
+        engines.append(e)
+        z0 += d
+    cl = slab.LocalSlabCluster(engines, preset)
+    cl.exchange_mask()
+    cl.exchange_populations()
+    cl.step(steps)
+    rho = np.concatenate([e.rho for e in engines])
+    u = np.concatenate([e.u for e in engines]).reshape(-1, 4)
+    np.testing.assert_array_equal(rho, o.density())
+    np.testing.assert_array_equal(u, o.velocity())
+    f = np.concatenate([e.populations().reshape(19, e.D, -1) for e in engines], axis=1).reshape(19, -1)
+    np.testing.assert_array_equal(f, o.populations())
+
+
+def test_empty_tunnel_wrap_rows(oracle):
+    """No obstacle: the outlet quirk rows (y = 0, y = H-1) and the first<->last layer wrap are live."""
+    from cfd_amd import slab
+    from oracle_slab import OracleSlabEngine
+    W, H, Dg, steps = 16, 6, 6, 9
+    o, mask = reference_run(oracle, W, H, Dg, 0, steps, [])
+    for splits in [(3, 3), (2, 2, 2), (6,)]:
+        engines, z0 = [], 0
+        for d in splits:
+            engines.append(OracleSlabEngine(W, H, Dg, z0, d, 0))
+            z0 += d
+        cl = slab.LocalSlabCluster(engines, 0)
+        cl.exchange_mask(); cl.exchange_populations(); cl.step(steps)
+        f = np.concatenate([e.populations().reshape(19, e.D, -1) for e in engines], axis=1).reshape(19, -1)
+        np.testing.assert_array_equal(f, o.populations(), err_msg=str(splits))
+
+
+def _gloo_rank(rank, world, port, preset, W, H, Dg, steps, mask, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cfd_amd import slab
+    from oracle_slab import OracleSlabEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z0, d = slab.slab_range(Dg, world, rank)
+    e = OracleSlabEngine(W, H, Dg, z0, d, preset)
+    e.set_solid(mask.reshape(Dg, H, W)[z0:z0 + d])
+    drv = slab.SlabSolver(e, preset, world, rank, slab.TorchP2P())
+    drv.exchange_mask()
+    drv.exchange_populations()
+    drv.step(steps)
+    out[rank] = (z0, d, e.rho.copy(), e.u.copy(), e.populations())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("preset,world", [(0, 2), (1, 2), (0, 3)])
+def test_gloo_ranks_equal_single_domain(oracle, preset, world):
+    import torch.multiprocessing as mp
+    W, H, Dg, steps = 24, 8, 9, 6
+    o, mask = reference_run(oracle, W, H, Dg, preset, steps, [(6, 0, 1, 5, 4, 7)])
+    port = 29600 + (os.getpid() % 200) + preset * 7 + world
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_rank, args=(world, port, preset, W, H, Dg, steps, mask, out), nprocs=world, join=True)
+    parts = [out[r] for r in range(world)]
+    rho = np.concatenate([p[2] for p in parts])
+    u = np.concatenate([p[3] for p in parts]).reshape(-1, 4)
+    f = np.concatenate([p[4].reshape(19, p[1], -1) for p in parts], axis=1).reshape(19, -1)
+    np.testing.assert_array_equal(rho, o.density())
+    np.testing.assert_array_equal(u, o.velocity())
+    np.testing.assert_array_equal(f, o.populations())
+
+
+def test_topology():
+    from cfd_amd import slab
+    assert [slab.slab_range(10, 3, r) for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
+    assert slab.neighbours(0, 4, 0) == (3, 1) and slab.neighbours(0, 4, 3) == (2, 0)   # ring
+    assert slab.neighbours(1, 4, 0) == (None, 1) and slab.neighbours(1, 4, 3) == (2, None)  # chain
+    assert slab.neighbours(1, 1, 0) == (None, None) and slab.neighbours(0, 1, 0) == (0, 0)
