@@ -260,6 +260,247 @@ __global__ __launch_bounds__(256) void k_stream_collide(
 }
 
 // ------------------------------------------------------------------------------------------
+// AA-pattern variant: ONE population buffer updated in place (half the memory of A/B).
+//
+// Let F_k(c) be the post-collision population k of cell c (what the A/B buffer holds).  The
+// single buffer M stores it in one of two layouts, alternating every step:
+//   after an ODD  step ("streamed"):  F_k(c) lives at M[k][c + c_k]
+//   after an EVEN step ("swapped"):   F_k(c) lives at M[inv k][c]
+// so an even step reads its own cell's slots and writes its own cell's slots, and an odd step
+// reads the neighbours' slots and writes exactly the slots it read.  Every branch of the
+// reference's boundary chain asks for some F_kk(cell) and is translated through the layout of the
+// moment; bounce-back and free-slip values sit in the solid neighbour's / the ghost shell's slots,
+// which no other thread touches, so the update is race-free.  The one exception is the outlet
+// branch (lbm_solver.cu:292-296), which copies from another FLUID cell of the x = W-1 column and
+// would race in place: those seven planes of that column are mirrored in a small double-buffered
+// side array `ob` that x = W-1 cells write each step and read the step after.
+// The buffer needs a ghost shell in x and y as well: Wp >= W+2 and H+2 rows per layer, addressed
+// linearly (x = -1 is the last pad slot of the previous row, y = -1 the last row of the previous
+// layer), which keeps x = 0 on a 128-byte boundary.
+// ------------------------------------------------------------------------------------------
+constexpr int OB_N = 7;
+constexpr int OB_PLANE[OB_N] = {2, 8, 9, 10, 12, 13, 14};
+__host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <= 10 ? pl - 7 : pl - 8); }
+
+template <int K>
+__device__ __forceinline__ long long dir_off(const Geo& g) {
+    return (long long)CZ[K] * g.layer + (long long)CY[K] * g.Wp + CX[K];
+}
+
+// where F_KK(own cell) is stored in the layout that PHASE reads
+template <int KK, int PHASE>
+__device__ __forceinline__ const float* aa_own_pop(const Geo& g, const float* M, long long own) {
+    return PHASE == 0 ? M + (long long)KK * g.plane + own + dir_off<KK>(g)   // streamed layout
+                      : M + (long long)INV[KK] * g.plane + own;             // swapped layout
+}
+// where F_K(own - c_K), the plainly pulled population, is stored
+template <int K, int PHASE>
+__device__ __forceinline__ const float* aa_pull_pop(const Geo& g, const float* M, long long own) {
+    return PHASE == 0 ? M + (long long)K * g.plane + own
+                      : M + (long long)INV[K] * g.plane + own - dir_off<K>(g);
+}
+
+template <int K>
+__device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __restrict__ ob_old, int y, int zl) {
+    int pl = K;
+    int ny = y - CY[K];
+    int nz = (zl - 1) - CZ[K];
+    if (ny < 0) { ny += g.H; nz -= 1; }
+    else if (ny >= g.H) { ny -= g.H; nz += 1; }
+    if (nz < 0) { nz += g.D; pl -= 1; }
+    else if (nz >= g.D) { nz -= g.D; pl += 1; }
+    return ob_old[((long long)ob_index(pl) * g.D + nz) * g.H + ny];
+}
+
+template <int PRESET, int K, int PHASE>
+__device__ __forceinline__ float aa_gather_general(const Geo& g, const float* M, const float* __restrict__ ob_old,
+                                                   const unsigned long long* __restrict__ mask, int x, int y,
+                                                   int zl, long long own, float inlet_e, float U) {
+    const unsigned code = classify_dir<PRESET, K>(g, mask, x, y, zl);
+    if (code == SRC_INLET) return weight(K) * inlet_e;
+    if (code == SRC_OUTLET) return aa_outlet_read<K>(g, ob_old, y, zl);
+    const float* p;
+    if (code == SRC_PULL) p = aa_pull_pop<K, PHASE>(g, M, own);
+    else if (code == SRC_CEIL_RFY) p = aa_own_pop<RFY[K], PHASE>(g, M, own);
+    else if (code == SRC_SIDE_RFZ) p = aa_own_pop<RFZ[K], PHASE>(g, M, own);
+    else p = aa_own_pop<INV[K], PHASE>(g, M, own);
+    float v = *p;
+    if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
+    return v;
+}
+
+template <int PRESET, int K, int PHASE, int TUNE>
+__device__ __forceinline__ float aa_gather_fast(const Geo& g, const float* M, const float* __restrict__ ob_old,
+                                                int x, int y, int zl, long long own, float inlet_e) {
+    constexpr int cx = CX[K];
+    const float* p = aa_pull_pop<K, PHASE>(g, M, own);
+    if (cx == 0) return ldf<TUNE>(p);
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
+        if (cx == 1) {
+            const float v = ldf<TUNE>(p);  // x = 0 reads a ghost slot: in bounds, discarded
+            return x == 0 ? weight(K) * inlet_e : v;
+        }
+        if (x == g.W - 1)  // interior tile: ny, nz are in range
+            return ob_old[((long long)ob_index(K) * g.D + (zl - 1 - CZ[K])) * g.H + (y - CY[K])];
+        return ldf<TUNE>(p);
+    } else {
+        const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
+        if (wall) return *aa_own_pop<INV[K], PHASE>(g, M, own);
+        return ldf<TUNE>(p);
+    }
+}
+
+template <int PRESET, int PHASE, int TUNE, int K>
+struct AaGather {
+    static __device__ __forceinline__ void fast(const Geo& g, const float* M, const float* ob, int x, int y, int zl,
+                                                long long own, float e, float* f) {
+        AaGather<PRESET, PHASE, TUNE, K - 1>::fast(g, M, ob, x, y, zl, own, e, f);
+        f[K] = aa_gather_fast<PRESET, K, PHASE, TUNE>(g, M, ob, x, y, zl, own, e);
+    }
+    static __device__ __forceinline__ void general(const Geo& g, const float* M, const float* ob,
+                                                   const unsigned long long* mask, int x, int y, int zl,
+                                                   long long own, float e, float U, float* f) {
+        AaGather<PRESET, PHASE, TUNE, K - 1>::general(g, M, ob, mask, x, y, zl, own, e, U, f);
+        f[K] = aa_gather_general<PRESET, K, PHASE>(g, M, ob, mask, x, y, zl, own, e, U);
+    }
+    static __device__ __forceinline__ void store(const Geo& g, float* M, long long own, const float* o) {
+        AaGather<PRESET, PHASE, TUNE, K - 1>::store(g, M, own, o);
+        float* dst = PHASE == 0 ? M + (long long)INV[K] * g.plane + own
+                                : M + (long long)K * g.plane + own + dir_off<K>(g);
+        stf<TUNE>(dst, o[K]);
+    }
+};
+template <int PRESET, int PHASE, int TUNE>
+struct AaGather<PRESET, PHASE, TUNE, -1> {
+    static __device__ __forceinline__ void fast(const Geo&, const float*, const float*, int, int, int, long long, float, float*) {}
+    static __device__ __forceinline__ void general(const Geo&, const float*, const float*, const unsigned long long*, int, int, int, long long, float, float, float*) {}
+    static __device__ __forceinline__ void store(const Geo&, float*, long long, const float*) {}
+};
+
+// PHASE 0: even step (reads the streamed layout, writes the swapped one); PHASE 1: odd step.
+template <int PRESET, int PHASE, int TUNE>
+__global__ __launch_bounds__(256) void k_aa_step(
+    float* M, const float* __restrict__ ob_old, float* __restrict__ ob_new,
+    const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
+    float* __restrict__ rho_out, float4* __restrict__ u_out, Geo g, Params p, int segsx_log2, int zrev,
+    int want_moments) {
+    const TileId t = tile_of_wave(segsx_log2);
+    const int y = t.y;
+    const int zl = 1 + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    if (t.xs >= g.Wt || y >= g.H) return;
+    const int x = t.xs * 64 + t.lane;
+    const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
+    if (x >= g.W) return;
+    const long long own = cell_off(g, x, y, zl);
+    const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+    const float inlet_e = inlet_bracket(p.U);
+    float f[Q];
+    if (flag == 0) {
+        AaGather<PRESET, PHASE, TUNE, Q - 1>::fast(g, M, ob_old, x, y, zl, own, inlet_e, f);
+    } else {
+        if (solid_at(g, mask, x, y, zl)) {
+            if (want_moments) {
+                rho_out[ridx] = 0.0f;
+                u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
+        AaGather<PRESET, PHASE, TUNE, Q - 1>::general(g, M, ob_old, mask, x, y, zl, own, inlet_e, p.U, f);
+    }
+    const Moments m = moments_of(f);
+    if (want_moments) {
+        rho_out[ridx] = m.rho;
+        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
+    }
+    float o[Q];
+    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
+    AaGather<PRESET, PHASE, TUNE, Q - 1>::store(g, M, own, o);
+    if (x == g.W - 1) {
+        const long long col = (long long)(zl - 1) * g.H + y;
+#pragma unroll
+        for (int i = 0; i < OB_N; i++) ob_new[(long long)i * g.D * g.H + col] = o[OB_PLANE[i]];
+    }
+}
+
+__global__ void k_ob_fill(float* __restrict__ a, float* __restrict__ b, long long per_plane) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_plane * OB_N) return;
+    const float w = weight(OB_PLANE[i / per_plane]);
+    a[i] = w;
+    b[i] = w;
+}
+
+// solid cells of the outlet column keep their frozen value in both side buffers
+__global__ void k_ob_sync(const float* __restrict__ cur, float* __restrict__ other,
+                          const unsigned long long* __restrict__ mask, Geo g) {
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= (long long)g.D * g.H) return;
+    const int z = (int)(col / g.H), y = (int)(col - (long long)z * g.H);
+    if (!solid_at(g, mask, g.W - 1, y, z + 1)) return;
+    for (int i = 0; i < OB_N; i++) other[(long long)i * g.D * g.H + col] = cur[(long long)i * g.D * g.H + col];
+}
+
+// A cell that the new mask turns from solid to fluid restarts from equilibrium (F_k = w_k): the
+// in-place scheme has nowhere to keep a solid cell's frozen populations (documented deviation from
+// the A/B scheme; identical to the reference whenever the cell was solid since init()).
+__global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsigned long long* __restrict__ prev,
+                                const unsigned long long* __restrict__ mask, Geo g, int phase) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    if (!solid_at(g, prev, x, y, z + 1) || solid_at(g, mask, x, y, z + 1)) return;
+    const long long own = cell_off(g, x, y, z + 1);
+    for (int k = 0; k < Q; k++) {
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        if (phase == 0) M[(long long)k * g.plane + own + d] = weight(k);
+        else M[(long long)INV[k] * g.plane + own] = weight(k);
+    }
+    if (x == g.W - 1)
+        for (int j = 0; j < OB_N; j++) ob_cur[(long long)j * g.D * g.H + (long long)z * g.H + y] = weight(OB_PLANE[j]);
+}
+
+// canonical f[k*n + idx] <-> the in-place layout of the moment
+__global__ void k_aa_export(const float* __restrict__ M, float* __restrict__ dense, Geo g, int phase) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    const long long own = cell_off(g, x, y, z + 1);
+    for (int k = 0; k < Q; k++) {
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        dense[(long long)k * n + i] = phase == 0 ? M[(long long)k * g.plane + own + d] : M[(long long)INV[k] * g.plane + own];
+    }
+}
+__global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, float* __restrict__ ob_b,
+                            const float* __restrict__ dense, Geo g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    const long long own = cell_off(g, x, y, z + 1);
+    for (int k = 0; k < Q; k++) {
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        M[(long long)k * g.plane + own + d] = dense[(long long)k * n + i];  // streamed layout
+    }
+    if (x == g.W - 1)
+        for (int j = 0; j < OB_N; j++) {
+            const float v = dense[(long long)OB_PLANE[j] * n + i];
+            ob_a[(long long)j * g.D * g.H + (long long)z * g.H + y] = v;
+            ob_b[(long long)j * g.D * g.H + (long long)z * g.H + y] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // set-up and read-back kernels
 // ------------------------------------------------------------------------------------------
 // k_init (lbm_solver.cu:37-64): equilibrium at rho = 1, u = 0 is f_k = w_k exactly.  Fills the
@@ -516,7 +757,14 @@ struct lbm_ctx {
     int segsx_log2 = 0;
     int split_phase = 0;
     int tune = 0;              // bit 0 nt loads, bit 1 sc1 stores, bit 2 alternate z direction per step
-    int zrev = 0;       // 0 idle, 1 boundary layers issued, 2 interior issued
+    int zrev = 0;
+    int scheme = LBM_SCHEME_AB;
+    int aa_phase = 0;          // AA: 0 = next step is even (buffer in the streamed layout)
+    float* alloc0 = nullptr;   // AA: start of the allocation (f[0] sits behind a front guard)
+    float* ob[2] = {nullptr, nullptr};
+    int ob_cur = 0;
+    unsigned long long* prev_mask = nullptr;
+    size_t mask_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t steps = 0, steps_at_begin = 0;
     double last_ms = 0.0;
@@ -571,9 +819,19 @@ static int refresh_mask_state(lbm_ctx* c) {
     else
         hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_WIND_TUNNEL_REF>, dim3(blocks_for(ntiles, 256)), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_sync_solid, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream,
-                       c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
-    HIPCHK(c, hipGetLastError());
+    if (c->scheme == LBM_SCHEME_AA) {
+        hipLaunchKernelGGL(k_aa_refluidize, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0],
+                           c->ob[c->ob_cur], c->prev_mask, c->mask, c->g, c->aa_phase);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(k_ob_sync, dim3(blocks_for((long long)c->g.D * c->g.H, 256)), dim3(256), 0, c->stream,
+                           c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->prev_mask, c->mask, c->mask_bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_sync_solid, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream,
+                           c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
+        HIPCHK(c, hipGetLastError());
+    }
     c->mask_dirty = false;
     return LBM_OK;
 }
@@ -599,6 +857,35 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
 #undef LBM_LAUNCH_T
 #undef LBM_LAUNCH
     HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
+static int launch_aa_step(lbm_ctx* c, int want_moments) {
+    const int segsx = 1 << c->segsx_log2;
+    dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), c->g.D);
+    const int zrev = (c->tune & 4) ? c->zrev : 0;
+#define LBM_AA(PRESET, PHASE, TUNE)                                                                               \
+    hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, c->stream, c->f[0], c->ob[c->ob_cur],  \
+                       c->ob[1 - c->ob_cur], c->mask, c->flags, c->rho, c->u, c->g, c->p, c->segsx_log2, zrev,     \
+                       want_moments)
+#define LBM_AA_T(PRESET, PHASE)                       \
+    switch (c->tune & 3) {                            \
+        case 0: LBM_AA(PRESET, PHASE, 0); break;      \
+        case 1: LBM_AA(PRESET, PHASE, 1); break;      \
+        case 2: LBM_AA(PRESET, PHASE, 2); break;      \
+        default: LBM_AA(PRESET, PHASE, 3); break;     \
+    }
+#define LBM_AA_P(PRESET) \
+    if (c->aa_phase == 0) { LBM_AA_T(PRESET, 0) } else { LBM_AA_T(PRESET, 1) }
+    if (c->preset == LBM_PRESET_CAVITY) { LBM_AA_P(LBM_PRESET_CAVITY) }
+    else { LBM_AA_P(LBM_PRESET_WIND_TUNNEL_REF) }
+#undef LBM_AA_P
+#undef LBM_AA_T
+#undef LBM_AA
+    HIPCHK(c, hipGetLastError());
+    c->aa_phase ^= 1;
+    c->ob_cur ^= 1;
+    c->zrev ^= 1;
     return LBM_OK;
 }
 
@@ -643,7 +930,10 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     }
     if (o.preset != LBM_PRESET_WIND_TUNNEL_REF && o.preset != LBM_PRESET_CAVITY)
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown preset %d", o.preset);
-    if (o.scheme != LBM_SCHEME_AB) return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
+    if (o.scheme != LBM_SCHEME_AB && o.scheme != LBM_SCHEME_AA)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
+    if (o.scheme == LBM_SCHEME_AA && o.depth_global > 0)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: the AA scheme does not support z-slabs yet (use LBM_SCHEME_AB)");
     int Dg = o.depth_global > 0 ? o.depth_global : depth;
     int z0 = o.depth_global > 0 ? o.z0 : 0;
     if (z0 < 0 || (long long)z0 + depth > Dg)
@@ -663,17 +953,23 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     Geo& g = c->g;
     g.W = width; g.H = height; g.D = depth; g.Dg = Dg; g.z0 = z0;
     g.slab = o.depth_global > 0 ? 1 : 0;
-    g.Wp = (width + 31) / 32 * 32;
+    c->scheme = o.scheme;
+    const bool aa = o.scheme == LBM_SCHEME_AA;
+    g.Wp = ((aa ? width + 2 : width) + 31) / 32 * 32;  // AA: ghost slots x = -1 and x = W in the row padding
     g.Wm = (width + 63) / 64;
     g.Wt = g.Wm;
-    g.layer = (long long)height * g.Wp;
+    g.layer = (long long)(aa ? height + 2 : height) * g.Wp;  // AA: ghost rows y = H and y = -1
     long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 3072) / 4;  // measured best of a 0..1 MiB sweep
+    const long long guard = aa ? g.Wp + 32 : 0;  // AA: (y = -1, z = -1) reaches one row before a plane
+    if (skew_floats < guard) skew_floats = guard;
     skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
     g.plane = (long long)(depth + 2) * g.layer + skew_floats;
     c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
     // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
-    c->tune = 7;
+    // In place (AA) the write-through stores lose: partial-line neighbour writes no longer combine
+    // in L2 (4.24 vs 5.39 TB/s), so AA keeps nt loads + nt stores + alternating z direction.
+    c->tune = o.scheme == LBM_SCHEME_AA ? 5 : 7;
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
     c->pop_bytes = (size_t)Q * g.plane * sizeof(float);
 
@@ -695,9 +991,20 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    CR(hipMalloc(&c->f[0], c->pop_bytes));
-    CR(hipMalloc(&c->f[1], c->pop_bytes));
     const size_t mask_bytes = (size_t)(depth + 2) * height * g.Wm * sizeof(unsigned long long);
+    c->mask_bytes = mask_bytes;
+    if (aa) {
+        CR(hipMalloc(&c->alloc0, c->pop_bytes + (size_t)guard * sizeof(float)));
+        c->f[0] = c->alloc0 + guard;
+        const size_t ob_bytes = (size_t)OB_N * depth * height * sizeof(float);
+        CR(hipMalloc(&c->ob[0], ob_bytes));
+        CR(hipMalloc(&c->ob[1], ob_bytes));
+        CR(hipMalloc(&c->prev_mask, mask_bytes));
+        CR(hipMemsetAsync(c->prev_mask, 0, mask_bytes, c->stream));
+    } else {
+        CR(hipMalloc(&c->f[0], c->pop_bytes));
+        CR(hipMalloc(&c->f[1], c->pop_bytes));
+    }
     CR(hipMalloc(&c->mask, mask_bytes));
     CR(hipMemsetAsync(c->mask, 0, mask_bytes, c->stream));  // d_solid.memset(0), lbm_solver.cu:415
     CR(hipMalloc(&c->flags, (size_t)depth * height * g.Wt));
@@ -712,7 +1019,9 @@ int lbm_destroy(lbm_ctx* c) {
     if (!c) return LBM_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->f[0]); hipFree(c->f[1]); hipFree(c->mask); hipFree(c->flags);
+    if (c->alloc0) hipFree(c->alloc0); else hipFree(c->f[0]);
+    hipFree(c->f[1]); hipFree(c->mask); hipFree(c->flags);
+    hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
     hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -723,9 +1032,18 @@ int lbm_destroy(lbm_ctx* c) {
 
 int lbm_init(lbm_ctx* c) {
     NEED(c);
-    const long long count = (long long)(c->g.D + 2) * c->g.layer;
-    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(count, 256), Q), dim3(256), 0, c->stream, c->f[0], c->f[1], c->g.plane, count);
+    // whole plane stride: the AA scheme's ghost slot (y = -1, z = -1) of plane k lies in the skew
+    // region behind plane k-1
+    const long long count = c->g.plane;
+    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(count, 256), Q), dim3(256), 0, c->stream, c->f[0],
+                       c->f[1] ? c->f[1] : c->f[0], c->g.plane, count);
     HIPCHK(c, hipGetLastError());
+    if (c->scheme == LBM_SCHEME_AA) {
+        const long long per = (long long)c->g.D * c->g.H;
+        hipLaunchKernelGGL(k_ob_fill, dim3(blocks_for(per * OB_N, 256)), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
+        HIPCHK(c, hipGetLastError());
+        c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
+    }
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
     c->curl_valid = false;
     return LBM_OK;
@@ -808,6 +1126,18 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step: a split step is in flight (lbm_step_finish missing)");
     int rc = refresh_mask_state(c);
     if (rc) return rc;
+    if (c->scheme == LBM_SCHEME_AA) {
+        // in place there is no previous buffer to recompute rho/u from: the last step of the batch
+        // writes them (20 B/cell once per call)
+        rc = ensure_field_buffers(c);
+        for (int s = 0; s < nsteps && !rc; s++) rc = launch_aa_step(c, s == nsteps - 1);
+        if (rc) return rc;
+        c->p_last = c->p;
+        c->steps += (uint64_t)nsteps;
+        c->fields = FIELDS_VALID;
+        c->curl_valid = false;
+        return LBM_OK;
+    }
     for (int s = 0; s < nsteps; s++) {
         rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D);
         if (rc) return rc;
@@ -922,15 +1252,43 @@ static int copy_populations(lbm_ctx* c, float* host, bool to_host) {
     return LBM_OK;
 }
 
+static int aa_copy_populations(lbm_ctx* c, float* host, bool to_host) {
+    const size_t bytes = (size_t)cells(c) * Q * sizeof(float);
+    float* dense = nullptr;
+    HIPCHK(c, hipMalloc(&dense, bytes));
+    hipError_t e = hipSuccess;
+    if (to_host) {
+        hipLaunchKernelGGL(k_aa_export, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0], dense, c->g, c->aa_phase);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host, dense, bytes, hipMemcpyDeviceToHost, c->stream);
+    } else {
+        e = hipMemcpyAsync(dense, host, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_aa_import, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0], c->ob[0], c->ob[1], dense, c->g);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dense);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "population copy: %s", hipGetErrorString(e));
+    if (!to_host) c->aa_phase = 0;
+    return LBM_OK;
+}
+
 int lbm_read_populations(lbm_ctx* c, float* f, size_t n19) {
     NEED(c);
     if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_read_populations: need %lld floats", cells(c) * Q);
+    if (c->scheme == LBM_SCHEME_AA) {
+        int rc = refresh_mask_state(c);
+        return rc ? rc : aa_copy_populations(c, f, true);
+    }
     return copy_populations(c, f, true);
 }
 
 int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     NEED(c);
     if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_write_populations: need %lld floats", cells(c) * Q);
+    if (c->scheme == LBM_SCHEME_AA) return aa_copy_populations(c, const_cast<float*>(f), false);
     int rc = LBM_OK;
     if (c->fields == FIELDS_STALE) {  // settle rho/u of the last step before touching solid cells
         rc = refresh_mask_state(c);
@@ -974,7 +1332,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->steps = c->steps;
     out->cells = (uint64_t)cells(c);
     out->bytes_per_cell = 2ull * Q * sizeof(float);
-    out->population_bytes = 2ull * c->pop_bytes;
+    out->population_bytes = (c->scheme == LBM_SCHEME_AA ? 1ull : 2ull) * c->pop_bytes;
     out->last_timed_ms = c->last_ms;
     out->last_timed_steps = c->last_steps;
     return LBM_OK;
@@ -1028,6 +1386,7 @@ int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
 }
 
 static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
+    if (c->scheme != LBM_SCHEME_AB) return fail(c, LBM_ERR_STATE, "%s: z-slabs need LBM_SCHEME_AB", who);
     if (!c->g.slab) return fail(c, LBM_ERR_STATE, "%s: context was not created as a slab (lbm_opts.depth_global = 0)", who);
     if (side != 0 && side != 1) return fail(c, LBM_ERR_INVALID, "%s: side must be 0 or 1", who);
     if (!p) return fail(c, LBM_ERR_INVALID, "%s: buffer is null", who);
@@ -1098,6 +1457,7 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
 
 int lbm_step_boundary_layers(lbm_ctx* c) {
     NEED(c);
+    if (c->scheme != LBM_SCHEME_AB) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: z-slabs need LBM_SCHEME_AB");
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
     int rc = refresh_mask_state(c);
     if (rc) return rc;

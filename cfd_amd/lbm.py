@@ -13,6 +13,8 @@ import numpy as np
 Q = 19
 PRESET_WIND_TUNNEL = 0
 PRESET_CAVITY = 1
+SCHEME_AB = 0
+SCHEME_AA = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
@@ -120,7 +122,7 @@ class Solver:
     compute_curl, add_solid, load_mesh, density / velocity / solid-mask read-back, settings."""
 
     def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
-                 stream=None, plane_skew_bytes=-1):
+                 stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB):
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
@@ -129,7 +131,7 @@ class Solver:
         o.struct_size = C.sizeof(Opts)
         o.device = device
         o.preset = preset
-        o.scheme = 0
+        o.scheme = scheme
         o.z0 = z0
         o.depth_global = depth_global
         o.stream = stream

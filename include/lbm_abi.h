@@ -51,8 +51,13 @@ typedef enum lbm_status {
  * for the pure-roofline configuration (BASELINE.json configs[1]). */
 enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
 
-/* Streaming schemes.  AB = pull, two population buffers (lbm_solver.cu:482-490). */
-enum { LBM_SCHEME_AB = 0 };
+/* Streaming schemes.  AB = pull, two population buffers (lbm_solver.cu:482-490).  AA = one
+ * buffer updated in place (even step: own cell read / swapped own cell write; odd step:
+ * neighbour read / neighbour write): same results, half the population memory; rho/u are written
+ * by the last step of each lbm_step() call; a cell that a later mask change turns from solid back
+ * to fluid restarts from equilibrium (there is no second buffer to keep its frozen values);
+ * z-slabs are not supported with AA yet. */
+enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1 };
 
 typedef struct lbm_opts {
     int32_t struct_size;   /* = sizeof(lbm_opts); lets the ABI grow */
