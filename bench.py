@@ -75,14 +75,13 @@ def main():
     torch.cuda.set_device(local_rank)
     W, H, D = args.size
     preset = lbm.PRESET_CAVITY if args.preset == "cavity" else lbm.PRESET_WIND_TUNNEL
-    stream = torch.cuda.current_stream().cuda_stream
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from cfd_amd import slab
-        eng = slab.HipSlabEngine(W, H, D * world, rank * D, D, preset, device=local_rank, stream=stream)
+        eng = slab.HipSlabEngine(W, H, D * world, rank * D, D, preset, device=local_rank)
         solver = eng.solver
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
@@ -90,7 +89,7 @@ def main():
         drv.exchange_populations()
         step = drv.step
     else:
-        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, stream=stream)
+        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank)
         solver.init()
         step = solver.step
 

@@ -208,18 +208,39 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
 // ------------------------------------------------------------------------------------------
 // the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
 // MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
+// MODE 2: step of the one or two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
+//         that also writes the outgoing halo messages, so no separate pack pass is needed.
 // ------------------------------------------------------------------------------------------
+// message layout: see k_halo_pack
+__device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
+                                          const float* v) {
+    const long long at = (long long)y * g.Wp + x;
+#pragma unroll
+    for (int j = 0; j < 5; j++) msg[(long long)j * g.layer + at] = v[side ? UP5[j] : DOWN5[j]];
+    if (x != g.W - 1) return;
+    float* tail = msg + 5 * g.layer;
+    if (side) {
+        if (y == g.H - 1) { tail[0] = v[10]; tail[1] = v[9]; }
+        tail[2 + y] = v[13];
+    } else if (y == 0) {
+        tail[0] = v[8];
+        tail[1] = v[9];
+    }
+}
+
 template <int PRESET, int MODE, int TUNE>
 __global__ __launch_bounds__(256) void k_stream_collide(
     const float* __restrict__ fin, float* __restrict__ fout,
     const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
     float* __restrict__ rho_out, float4* __restrict__ u_out,
-    Geo g, Params p, int zl_begin, int segsx_log2, int zrev) {
+    Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
+    int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top) {
     const TileId t = tile_of_wave(segsx_log2);
     const int y = t.y;
     // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
     // starts on the layers the previous step wrote last (still in the Infinity Cache)
-    const int zl = zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    const int zl = MODE == 2 ? (blockIdx.z == 0 ? zl_begin : zl_second)
+                             : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
@@ -240,6 +261,11 @@ __global__ __launch_bounds__(256) void k_stream_collide(
                 rho_out[ridx] = 0.0f;
                 u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
+                for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
+                if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
+                if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
+            }
             return;
         }
         GatherAll<PRESET, Q - 1>::general(g, fin, mask, x, y, zl, own, inlet_e, p.U, f);
@@ -257,6 +283,10 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     float* dst = fout + own;
 #pragma unroll
     for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
+    if (MODE == 2) {
+        if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, o);
+        if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -683,6 +713,30 @@ __global__ void k_halo_unpack(float* __restrict__ f, const float* __restrict__ m
     }
 }
 
+__global__ void k_halo_unpack2(float* __restrict__ f, const float* __restrict__ from_below,
+                               const float* __restrict__ from_above, Geo g) {
+    const int side = blockIdx.y / 6;
+    const float* msg = side ? from_above : from_below;
+    if (!msg) return;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y % 6;
+    const int zl = side ? g.D + 1 : 0;
+    if (j < 5) {
+        if (i < g.layer) f[(long long)halo_plane(1 - side, j) * g.plane + (long long)zl * g.layer + i] = msg[(long long)j * g.layer + i];
+        return;
+    }
+    const float* tail = msg + 5 * g.layer;
+    if (side == 0) {
+        if (i >= g.H + 2) return;
+        if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
+        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[1];
+        else f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)] = tail[i];
+    } else {
+        if (i == 0) f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[0];
+        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[1];
+    }
+}
+
 // one layer of the packed mask <-> dense u8 (ghost exchange of the static mask)
 __global__ void k_mask_layer_get(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g, int zl) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -740,6 +794,7 @@ struct lbm_ctx {
     int device = 0;
     int preset = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_b = nullptr;  // optional caller-owned stream for the slab-boundary layers
     bool own_stream = false;
     float* f[2] = {nullptr, nullptr};
     int cur = 0;
@@ -837,14 +892,16 @@ static int refresh_mask_state(lbm_ctx* c) {
 }
 
 template <int MODE>
-static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers) {
+static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers,
+                                 int zl_second = 0, float* msg_bottom = nullptr, float* msg_top = nullptr) {
     if (nlayers <= 0) return LBM_OK;
+    hipStream_t stream = (MODE == 2 && c->stream_b) ? c->stream_b : c->stream;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
     const int zrev = (MODE == 0 && (c->tune & 4)) ? c->zrev : 0;
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
-    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), 0, c->stream, fin, fout, c->mask, \
-                       c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev)
+    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), 0, stream, fin, fout, c->mask, \
+                       c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top)
 #define LBM_LAUNCH_T(PRESET)                          \
     switch (c->tune & 3) {                            \
         case 0: LBM_LAUNCH(PRESET, 0); break;         \
@@ -987,6 +1044,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     } while (0)
     if (o.stream) {
         c->stream = (hipStream_t)o.stream;
+        c->stream_b = (hipStream_t)o.boundary_stream;
     } else {
         CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
@@ -1455,16 +1513,36 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
     return LBM_OK;
 }
 
-int lbm_step_boundary_layers(lbm_ctx* c) {
+int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
     NEED(c);
     if (c->scheme != LBM_SCHEME_AB) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: z-slabs need LBM_SCHEME_AB");
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
+    if ((d_msg_bottom || d_msg_top) && !c->g.slab)
+        return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: messages need a slab context");
+    const bool was_dirty = c->mask_dirty;
     int rc = refresh_mask_state(c);
     if (rc) return rc;
-    rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, 1);
-    if (!rc && c->g.D > 1) rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, c->g.D, 1);
+    if (was_dirty && c->stream_b) {  // the set-up kernels ran on the main stream: order the side stream behind them
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev1, 0));
+    }
+    // one launch for both boundary layers; it writes the outgoing messages as it goes
+    rc = launch_stream_collide<2>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D > 1 ? 2 : 1, c->g.D,
+                                  d_msg_bottom, d_msg_top);
     if (rc) return rc;
     c->split_phase = 1;
+    return LBM_OK;
+}
+
+int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_from_above) {
+    NEED(c);
+    if (!d_from_below && !d_from_above) return LBM_OK;
+    int rc = halo_args_ok(c, 0, d_from_below ? d_from_below : d_from_above, "lbm_halo_unpack_both");
+    if (rc) return rc;
+    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, c->stream, dst, d_from_below, d_from_above, c->g);
+    HIPCHK(c, hipGetLastError());
     return LBM_OK;
 }
 

@@ -30,7 +30,8 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("preset", C.c_int32),
                 ("scheme", C.c_int32), ("z0", C.c_int32), ("depth_global", C.c_int32),
                 ("stream", C.c_void_p), ("plane_skew_bytes", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("reserved0", C.c_int32), ("boundary_stream", C.c_void_p),
+                ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):
@@ -76,7 +77,8 @@ SIGNATURES = {
     "lbm_halo_unpack": ([_ctx, C.c_int, C.c_void_p], C.c_int),
     "lbm_halo_get_mask_layer": ([_ctx, C.c_int, _up, C.c_size_t], C.c_int),
     "lbm_halo_set_mask_ghost": ([_ctx, C.c_int, _up, C.c_size_t], C.c_int),
-    "lbm_step_boundary_layers": ([_ctx], C.c_int),
+    "lbm_halo_unpack_both": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
+    "lbm_step_boundary_layers": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_step_interior_layers": ([_ctx], C.c_int),
     "lbm_step_finish": ([_ctx], C.c_int),
 }
@@ -122,7 +124,7 @@ class Solver:
     compute_curl, add_solid, load_mesh, density / velocity / solid-mask read-back, settings."""
 
     def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
-                 stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB):
+                 stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB, boundary_stream=None):
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
@@ -136,6 +138,7 @@ class Solver:
         o.depth_global = depth_global
         o.stream = stream
         o.plane_skew_bytes = plane_skew_bytes
+        o.boundary_stream = boundary_stream
         self._ctx = _ctx()
         rc = self._lib.lbm_create(C.byref(self._ctx), W, H, D, C.byref(o))
         if rc != 0:

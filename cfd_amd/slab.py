@@ -12,6 +12,8 @@ The engine (HIP context, or an oracle-backed stand-in in the CPU tests) and the 
 through torch.distributed, gloo in CPU tests, or a local copy between slabs that live in one
 process) are both pluggable; the schedule and the neighbour topology live here.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -41,13 +43,29 @@ def neighbours(preset, world, rank):
 class HipSlabEngine:
     """One HIP context owning global layers [z0, z0+D)."""
 
-    def __init__(self, W, H, depth_global, z0, D, preset, device=-1, stream=None):
-        self.solver = lbm.Solver(W, H, D, preset=preset, device=device, z0=z0,
-                                 depth_global=depth_global, stream=stream)
+    def __init__(self, W, H, depth_global, z0, D, preset, device=-1, two_streams=False):
+        self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        # The context runs on torch streams of its own (non-null handles: handing over the legacy
+        # default stream, handle 0, would make the library create a private stream that
+        # torch.distributed knows nothing about).  `stream` carries the interior update and the
+        # unpack; `bstream` (high priority) carries the boundary layers, and the driver makes it
+        # torch's current stream around the exchange so RCCL orders itself behind them -- the
+        # boundary layers and the messages then run BESIDE the interior kernel, not before it.
+        self.stream = torch.cuda.Stream(device=self.device)
+        mode = os.environ.get("LBM_SLAB_STREAMS", "2" if two_streams else "1")
+        two_streams = mode in ("2", "2p")
+        self.bstream = None
+        if two_streams:
+            self.bstream = torch.cuda.Stream(device=self.device, priority=-1 if mode == "2p" else 0)
+        self.solver = lbm.Solver(W, H, D, preset=preset, device=self.device.index, z0=z0,
+                                 depth_global=depth_global, stream=self.stream.cuda_stream,
+                                 boundary_stream=self.bstream.cuda_stream if two_streams else None)
         self._lib = self.solver._lib
         self._ctx = self.solver._ctx
         self.W, self.H, self.D, self.z0 = W, H, D, z0
-        self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
 
     def message_floats(self):
         import ctypes as C
@@ -56,10 +74,12 @@ class HipSlabEngine:
         return n.value
 
     def new_message(self):
-        return torch.zeros(self.message_floats(), dtype=torch.float32, device=self.device)
+        with self.stream_ctx():
+            return torch.zeros(self.message_floats(), dtype=torch.float32, device=self.device)
 
     def new_mask_layer(self):
-        return torch.zeros(self.W * self.H, dtype=torch.uint8, device=self.device)
+        with self.stream_ctx():
+            return torch.zeros(self.W * self.H, dtype=torch.uint8, device=self.device)
 
     def halo_pack(self, side, msg):
         self.solver._chk(self._lib.lbm_halo_pack(self._ctx, side, msg.data_ptr()))
@@ -80,11 +100,21 @@ class HipSlabEngine:
         self.solver._chk(self._lib.lbm_halo_set_mask_ghost(
             self._ctx, side, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size))
 
-    def step_boundary(self):
-        self.solver._chk(self._lib.lbm_step_boundary_layers(self._ctx))
+    def step_boundary(self, msg_bottom=None, msg_top=None):
+        """boundary layers; the outgoing messages are written by the same launch"""
+        self.solver._chk(self._lib.lbm_step_boundary_layers(
+            self._ctx, None if msg_bottom is None else msg_bottom.data_ptr(),
+            None if msg_top is None else msg_top.data_ptr()))
+
+    def halo_unpack_both(self, from_below, from_above):
+        self.solver._chk(self._lib.lbm_halo_unpack_both(
+            self._ctx, None if from_below is None else from_below.data_ptr(),
+            None if from_above is None else from_above.data_ptr()))
 
     def step_interior(self):
         self.solver._chk(self._lib.lbm_step_interior_layers(self._ctx))
+
+    step_phase_interior = step_interior
 
     def step_finish(self):
         self.solver._chk(self._lib.lbm_step_finish(self._ctx))
@@ -135,8 +165,25 @@ class SlabSolver:
         return [(send[SIDE_TOP], self.up, recv[SIDE_BOTTOM], self.down),
                 (send[SIDE_BOTTOM], self.down, recv[SIDE_TOP], self.up)]
 
+    def _ctx(self):
+        import contextlib
+        return self.e.stream_ctx() if hasattr(self.e, "stream_ctx") else contextlib.nullcontext()
+
     def exchange_mask(self):
         """Static ghost layers of the solid mask; call after the mask changed on any rank."""
+        with self._ctx():
+            self._exchange_mask()
+
+    def exchange_populations(self):
+        """Fill the ghost layers from the current state (after init / set_populations)."""
+        with self._ctx():
+            self._exchange_populations()
+
+    def step(self, nsteps=1):
+        with self._ctx():
+            self._step(nsteps)
+
+    def _exchange_mask(self):
         e = self.e
         send = [None, None]
         recv = [e.new_mask_layer(), e.new_mask_layer()]
@@ -153,8 +200,7 @@ class SlabSolver:
         if up is not None:
             e.set_mask_ghost(SIDE_TOP, recv[SIDE_TOP].cpu().numpy())
 
-    def exchange_populations(self):
-        """Fill the ghost layers from the current state (after init / set_populations)."""
+    def _exchange_populations(self):
         e = self.e
         e.halo_pack(SIDE_BOTTOM, self.send[SIDE_BOTTOM])
         e.halo_pack(SIDE_TOP, self.send[SIDE_TOP])
@@ -164,19 +210,33 @@ class SlabSolver:
         if self.up is not None:
             e.halo_unpack(SIDE_TOP, self.recv[SIDE_TOP])
 
-    def step(self, nsteps=1):
+    def _step(self, nsteps=1):
         e = self.e
+        main = getattr(e, "stream", None)
+        side = getattr(e, "bstream", None)
+        msg_b = self.send[SIDE_BOTTOM] if self.down is not None else None
+        msg_t = self.send[SIDE_TOP] if self.up is not None else None
+        rcv_b = self.recv[SIDE_BOTTOM] if self.down is not None else None
+        rcv_t = self.recv[SIDE_TOP] if self.up is not None else None
         for _ in range(nsteps):
-            e.step_boundary()
-            e.halo_pack(SIDE_BOTTOM, self.send[SIDE_BOTTOM])
-            e.halo_pack(SIDE_TOP, self.send[SIDE_TOP])
-            h = self.t.exchange(self._items(self.send, self.recv))   # travels while ...
-            e.step_interior()                                        # ... the interior updates
-            self.t.wait(h)
-            if self.down is not None:
-                e.halo_unpack(SIDE_BOTTOM, self.recv[SIDE_BOTTOM])
-            if self.up is not None:
-                e.halo_unpack(SIDE_TOP, self.recv[SIDE_TOP])
+            if side is None:
+                # one stream: boundary layers, then the exchange travels while the interior updates
+                e.step_boundary(msg_b, msg_t)
+                h = self.t.exchange(self._items(self.send, self.recv))
+                e.step_interior()
+                self.t.wait(h)
+            else:
+                # two streams: boundary layers + exchange on the side stream, interior on the main
+                # stream at the same time
+                side.wait_stream(main)                 # previous step's unpack / swap is done
+                with torch.cuda.stream(side):
+                    e.step_boundary(msg_b, msg_t)      # library launches on the side stream
+                    h = self.t.exchange(self._items(self.send, self.recv))
+                e.step_phase_interior()
+                with torch.cuda.stream(side):
+                    self.t.wait(h)
+                main.wait_stream(side)
+            e.halo_unpack_both(rcv_b, rcv_t)
             e.step_finish()
 
 
@@ -232,9 +292,7 @@ class LocalSlabCluster:
     def step(self, nsteps=1):
         for _ in range(nsteps):
             for r, e in enumerate(self.engines):
-                e.step_boundary()
-                e.halo_pack(SIDE_BOTTOM, self.send[r][SIDE_BOTTOM])
-                e.halo_pack(SIDE_TOP, self.send[r][SIDE_TOP])
+                e.step_boundary(self.send[r][SIDE_BOTTOM], self.send[r][SIDE_TOP])
             for e in self.engines:
                 e.step_interior()
             self._sync()

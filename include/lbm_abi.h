@@ -70,7 +70,12 @@ typedef struct lbm_opts {
     int32_t depth_global;
     void*   stream;        /* hipStream_t to run on; NULL = the context creates its own */
     int32_t plane_skew_bytes; /* extra bytes between population planes; -1 = library default */
-    int32_t reserved[7];
+    int32_t reserved0;
+    /* optional second hipStream_t (ideally high priority) for lbm_step_boundary_layers, so the
+     * boundary layers and the halo exchange run beside the interior update instead of in front of
+     * it; the CALLER orders the two streams (see cfd_amd/slab.py).  NULL = use `stream`. */
+    void*   boundary_stream;
+    int32_t reserved[4];
 } lbm_opts;
 
 /* Per-context counters for benches (device time is measured with HIP events on the
@@ -181,10 +186,14 @@ int lbm_halo_unpack(lbm_ctx* ctx, int side, const float* d_message);
  * boundary layer on `side` as uint8[W*H], and the neighbour's layer to install as the ghost. */
 int lbm_halo_get_mask_layer(lbm_ctx* ctx, int side, uint8_t* layer, size_t n);
 int lbm_halo_set_mask_ghost(lbm_ctx* ctx, int side, const uint8_t* layer, size_t n);
+/* Both received messages in one launch (either may be NULL). */
+int lbm_halo_unpack_both(lbm_ctx* ctx, const float* d_from_below, const float* d_from_above);
 /* One step split for overlap: the two boundary layers first (their results feed the messages),
  * then the interior layers while the messages travel, then the A/B swap.
- * lbm_step(ctx, 1) == boundary + interior + finish. */
-int lbm_step_boundary_layers(lbm_ctx* ctx);
+ * lbm_step(ctx, 1) == boundary + interior + finish.  lbm_step_boundary_layers also writes the
+ * outgoing bottom / top messages (what lbm_halo_pack(0/1) would gather afterwards) straight into
+ * the given device buffers when they are not NULL, saving the pack passes. */
+int lbm_step_boundary_layers(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top);
 int lbm_step_interior_layers(lbm_ctx* ctx);
 int lbm_step_finish(lbm_ctx* ctx);
 

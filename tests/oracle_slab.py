@@ -36,11 +36,21 @@ class OracleSlabEngine:
         O.lib().orc_step_slab(O._fp(fin), O._fp(fout), O._fp(self.rho), O._fp(self.u), O._up(self.solid),
                               self.W, self.H, self.D, self.Dg, self.z0, *self.params, self.preset, zb, ze)
 
-    def step_boundary(self):
+    def step_boundary(self, msg_bottom=None, msg_top=None):
         self._run(1, 2)
         if self.D > 1:
             self._run(self.D, self.D + 1)
         self.phase = 1
+        if msg_bottom is not None:
+            self.halo_pack(0, msg_bottom)
+        if msg_top is not None:
+            self.halo_pack(1, msg_top)
+
+    def halo_unpack_both(self, from_below, from_above):
+        if from_below is not None:
+            self.halo_unpack(0, from_below)
+        if from_above is not None:
+            self.halo_unpack(1, from_above)
 
     def step_interior(self):
         self._run(2, self.D)
