@@ -41,12 +41,20 @@ struct Geo {
     int W, H, D;        // owned extent of this context
     int Dg, z0;         // global depth, global z of owned layer 0
     int slab;           // 1: one z-slab of a taller domain (ghost layers are fed by the halo exchange)
-    int Wp;             // floats per row (multiple of 32)
+    int Wp;             // floats per row of one population (multiple of 32: rows start on 128-byte lines)
     int Wm;             // 64-bit mask words per row
     int Wt;             // 64-cell tiles per row (= Wm)
-    long long layer;    // floats per z layer (H*Wp)
-    long long plane;    // floats between consecutive population planes
+    long long row;      // floats between consecutive y rows of one population
+    long long layer;    // floats between consecutive z layers of one population
+    long long plane;    // floats between consecutive populations of one cell
+    long long mlayer;   // floats per population layer inside a halo message (H*Wp)
 };
+// Two layouts share every kernel through these strides:
+//   LBM_LAYOUT_PLANES  [k][z][y][x] : row = Wp,    layer = rows*Wp,  plane = (D+2)*layer + skew
+//   LBM_LAYOUT_ROWS    [z][y][k][x] : plane = Wp,  row = 19*Wp,      layer = rows*row
+// In the row-interleaved form the 19 runs of one (y,z) row are one contiguous 19*Wp*4-byte chunk:
+// a step writes whole chunks and reads 1-3 KB pieces of nine neighbouring chunks, which streams
+// 6-7 % faster from HBM than 19+19 far-apart planes (profiles/r01_tuning.md, tools/membench5/6).
 
 struct Params {
     float U, omega_shear, omega_bulk;
@@ -54,7 +62,7 @@ struct Params {
 
 // device address of cell (x, y, zl) inside a plane; zl = local layer index incl. ghost (owned: 1..D)
 __device__ __forceinline__ long long cell_off(const Geo& g, int x, int y, int zl) {
-    return (long long)zl * g.layer + (long long)y * g.Wp + x;
+    return (long long)zl * g.layer + (long long)y * g.row + x;
 }
 
 __device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long* __restrict__ mask,
@@ -77,9 +85,10 @@ __device__ __forceinline__ void stf(float* p, float v) {
 // Which branch of the reference chain (lbm_solver.cu:283-318) feeds direction K of the fluid cell
 // (x, y, zl).  Single source of truth for the step kernel, the moment kernel and
 // lbm_read_classification.
-template <int PRESET, int K>
-__device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned long long* __restrict__ mask,
-                                                 int x, int y, int zl) {
+// `nb_solid()` answers "is the cell this direction pulls from solid?"; it is only asked when that
+// cell exists.
+template <int PRESET, int K, class NbSolid>
+__device__ __forceinline__ unsigned classify_with(const Geo& g, int x, int y, int zl, NbSolid nb_solid) {
     constexpr int cx = CX[K], cy = CY[K], cz = CZ[K];
     const int nx = x - cx, ny = y - cy;
     const int nzg = (zl - 1) + g.z0 - cz;
@@ -96,7 +105,51 @@ __device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned lo
         if (cz != 0 && (nzg < 0 || nzg >= g.Dg)) return SRC_SIDE_RFZ;
     }
     if (K == 0) return SRC_PULL;
-    return solid_at(g, mask, nx, ny, zl - cz) ? SRC_SOLID_BB : SRC_PULL;
+    return nb_solid() ? SRC_SOLID_BB : SRC_PULL;
+}
+
+// per-cell form: the neighbour's bit is read from the packed mask in memory
+template <int PRESET, int K>
+__device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                 int x, int y, int zl) {
+    return classify_with<PRESET, K>(g, x, y, zl, [&] { return solid_at(g, mask, x - CX[K], y - CY[K], zl - CZ[K]); });
+}
+
+// Per-tile form used by the step kernels: the solid bits of the 3 x 3 rows around one 64-cell
+// tile are fetched ONCE into wave-uniform registers (scalar loads), so the 19 directions are
+// classified without a memory round trip each and the 19 population loads issue back to back.
+struct TileMask {
+    unsigned long long w[3][3];  // [dz+1][dy+1]: cells x0 .. x0+63 of row (y+dy, zl+dz); 0 where that row does not exist
+    unsigned left, right;        // bit 3*(dz+1)+(dy+1): cell x0-1 / x0+64 of the same row
+};
+__device__ __forceinline__ TileMask load_tile_mask(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                   int xs, int y, int zl) {
+    TileMask t;
+    t.left = 0; t.right = 0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            const bool ok = yy >= 0 && yy < g.H;  // layers zl-1 .. zl+1 always exist (ghost layers)
+            const unsigned long long* r = mask + ((long long)(zl + dz) * g.H + (ok ? yy : y)) * g.Wm;
+            const unsigned long long w = r[xs];
+            const unsigned long long wl = r[xs > 0 ? xs - 1 : xs];
+            const unsigned long long wr = r[xs + 1 < g.Wm ? xs + 1 : xs];
+            t.w[dz + 1][dy + 1] = ok ? w : 0ull;
+            const int bit = 3 * (dz + 1) + (dy + 1);
+            if (ok && xs > 0) t.left |= (unsigned)(wl >> 63) << bit;
+            if (ok && xs + 1 < g.Wm) t.right |= (unsigned)(wr & 1ull) << bit;
+        }
+    return t;
+}
+template <int K>
+__device__ __forceinline__ bool tile_nb_solid(const TileMask& t, int lane) {
+    constexpr int iz = 1 - CZ[K], iy = 1 - CY[K], bit = 3 * iz + iy;
+    unsigned long long w = t.w[iz][iy];
+    if (CX[K] == 1) w = (w << 1) | (unsigned long long)((t.left >> bit) & 1u);           // neighbour x-1
+    if (CX[K] == -1) w = (w >> 1) | ((unsigned long long)((t.right >> bit) & 1u) << 63);  // neighbour x+1
+    return (w >> lane) & 1ull;
 }
 
 // Outlet branch (lbm_solver.cu:292-296): the reference indexes f_in[k*n + nz*W*H + ny*W + (W-1)]
@@ -104,7 +157,7 @@ __device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned lo
 // off the z end carries into the neighbouring population plane (quirk Q2).  Our planes are padded,
 // so the carry is applied in logical coordinates.
 template <int K>
-__device__ __forceinline__ float outlet_read(const Geo& g, const float* __restrict__ fin, int y, int zl) {
+__device__ __forceinline__ long long outlet_off(const Geo& g, int y, int zl) {
     int pl = K;
     int ny = y - CY[K];
     int nzg = (zl - 1) + g.z0 - CZ[K];
@@ -115,24 +168,30 @@ __device__ __forceinline__ float outlet_read(const Geo& g, const float* __restri
     if (nzg < 0) { pl -= 1; if (!g.slab) nzg += g.Dg; }
     else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nzg -= g.Dg; }
     const int nzl = nzg - g.z0 + 1;
-    return fin[(long long)pl * g.plane + cell_off(g, g.W - 1, ny, nzl)];
+    return (long long)pl * g.plane + cell_off(g, g.W - 1, ny, nzl);
+}
+template <int K>
+__device__ __forceinline__ float outlet_read(const Geo& g, const float* __restrict__ fin, int y, int zl) {
+    return fin[outlet_off<K>(g, y, zl)];
 }
 
-// full boundary chain for one direction, per lane
+// full boundary chain for one direction, per lane: the branch is turned into an address by
+// selects, so every lane issues exactly one load and no load waits for another
 template <int PRESET, int K>
-__device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin,
-                                                const unsigned long long* __restrict__ mask,
-                                                int x, int y, int zl, long long own, float inlet_e, float U) {
-    const unsigned code = classify_dir<PRESET, K>(g, mask, x, y, zl);
-    if (code == SRC_INLET) return weight(K) * inlet_e;
-    if (code == SRC_OUTLET) return outlet_read<K>(g, fin, y, zl);
-    int pl = K;
-    long long off = own;
-    if (code == SRC_PULL) off = cell_off(g, x - CX[K], y - CY[K], zl - CZ[K]);
-    else if (code == SRC_CEIL_RFY) pl = RFY[K];
-    else if (code == SRC_SIDE_RFZ) pl = RFZ[K];
-    else pl = INV[K];  // floor / solid / wall / lid bounce-back
-    float v = fin[(long long)pl * g.plane + off];
+__device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
+                                                int lane, int x, int y, int zl, long long own, float inlet_e, float U) {
+    const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
+    // own-cell sources: ceiling / side mirror, bounce-back (floor, solid, wall, lid); an inlet lane
+    // loads its own slot and discards it
+    const int pl = code == SRC_CEIL_RFY ? RFY[K] : (code == SRC_SIDE_RFZ ? RFZ[K] : (code == SRC_INLET ? K : INV[K]));
+    long long a = (long long)pl * g.plane + own;
+    if (code == SRC_PULL) a = (long long)K * g.plane + own - ((long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K]);
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) {
+        const long long ao = outlet_off<K>(g, y, zl);  // wave-uniform
+        if (code == SRC_OUTLET) a = ao;
+    }
+    float v = fin[a];
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == 1 && code == SRC_INLET) v = weight(K) * inlet_e;
     if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
     return v;
 }
@@ -144,7 +203,7 @@ __device__ __forceinline__ float gather_fast(const Geo& g, const float* __restri
                                              int x, int y, int zl, long long own, float inlet_e) {
     constexpr int cx = CX[K];
     const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
-                       (long long)(y - CY[K]) * g.Wp;
+                       (long long)(y - CY[K]) * g.row;
     if (cx == 0) return ldf<TUNE>(row + x);
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
         if (cx == 1) {
@@ -168,11 +227,11 @@ struct GatherAll {
         GatherAll<PRESET, K - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
         f[K] = gather_fast<PRESET, K, TUNE>(g, fin, x, y, zl, own, inlet_e);
     }
-    static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin,
-                                                   const unsigned long long* __restrict__ mask, int x, int y,
-                                                   int zl, long long own, float inlet_e, float U, float* f) {
-        GatherAll<PRESET, K - 1>::general(g, fin, mask, x, y, zl, own, inlet_e, U, f);
-        f[K] = gather_general<PRESET, K>(g, fin, mask, x, y, zl, own, inlet_e, U);
+    static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
+                                                   int lane, int x, int y, int zl, long long own, float inlet_e,
+                                                   float U, float* f) {
+        GatherAll<PRESET, K - 1>::general(g, fin, t, lane, x, y, zl, own, inlet_e, U, f);
+        f[K] = gather_general<PRESET, K>(g, fin, t, lane, x, y, zl, own, inlet_e, U);
     }
     static __device__ __forceinline__ void classify(const Geo& g, const unsigned long long* __restrict__ mask,
                                                     int x, int y, int zl, unsigned char* out) {
@@ -184,8 +243,8 @@ template <int PRESET>
 struct GatherAll<PRESET, -1> {
     template <int TUNE>
     static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
-    static __device__ __forceinline__ void general(const Geo&, const float*, const unsigned long long*, int, int,
-                                                   int, long long, float, float, float*) {}
+    static __device__ __forceinline__ void general(const Geo&, const float*, const TileMask&, int, int, int, int,
+                                                   long long, float, float, float*) {}
     static __device__ __forceinline__ void classify(const Geo&, const unsigned long long*, int, int, int,
                                                     unsigned char*) {}
 };
@@ -216,9 +275,9 @@ __device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg,
                                           const float* v) {
     const long long at = (long long)y * g.Wp + x;
 #pragma unroll
-    for (int j = 0; j < 5; j++) msg[(long long)j * g.layer + at] = v[side ? UP5[j] : DOWN5[j]];
+    for (int j = 0; j < 5; j++) msg[(long long)j * g.mlayer + at] = v[side ? UP5[j] : DOWN5[j]];
     if (x != g.W - 1) return;
-    float* tail = msg + 5 * g.layer;
+    float* tail = msg + 5 * g.mlayer;
     if (side) {
         if (y == g.H - 1) { tail[0] = v[10]; tail[1] = v[9]; }
         tail[2 + y] = v[13];
@@ -253,7 +312,8 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     if (flag == 0) {
         GatherAll<PRESET, Q - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
     } else {
-        if (solid_at(g, mask, x, y, zl)) {
+        const TileMask tm = load_tile_mask(g, mask, t.xs, y, zl);
+        if ((tm.w[1][1] >> t.lane) & 1ull) {
             // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
             // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
             if (MODE == 1) {
@@ -268,7 +328,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
             }
             return;
         }
-        GatherAll<PRESET, Q - 1>::general(g, fin, mask, x, y, zl, own, inlet_e, p.U, f);
+        GatherAll<PRESET, Q - 1>::general(g, fin, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
     }
 
     const Moments m = moments_of(f);
@@ -314,7 +374,7 @@ __host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <=
 
 template <int K>
 __device__ __forceinline__ long long dir_off(const Geo& g) {
-    return (long long)CZ[K] * g.layer + (long long)CY[K] * g.Wp + CX[K];
+    return (long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K];
 }
 
 // where F_KK(own cell) is stored in the layout that PHASE reads
@@ -344,9 +404,9 @@ __device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __res
 
 template <int PRESET, int K, int PHASE>
 __device__ __forceinline__ float aa_gather_general(const Geo& g, const float* M, const float* __restrict__ ob_old,
-                                                   const unsigned long long* __restrict__ mask, int x, int y,
+                                                   const TileMask& t, int lane, int x, int y,
                                                    int zl, long long own, float inlet_e, float U) {
-    const unsigned code = classify_dir<PRESET, K>(g, mask, x, y, zl);
+    const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
     if (code == SRC_INLET) return weight(K) * inlet_e;
     if (code == SRC_OUTLET) return aa_outlet_read<K>(g, ob_old, y, zl);
     const float* p;
@@ -388,10 +448,10 @@ struct AaGather {
         f[K] = aa_gather_fast<PRESET, K, PHASE, TUNE>(g, M, ob, x, y, zl, own, e);
     }
     static __device__ __forceinline__ void general(const Geo& g, const float* M, const float* ob,
-                                                   const unsigned long long* mask, int x, int y, int zl,
+                                                   const TileMask& t, int lane, int x, int y, int zl,
                                                    long long own, float e, float U, float* f) {
-        AaGather<PRESET, PHASE, TUNE, K - 1>::general(g, M, ob, mask, x, y, zl, own, e, U, f);
-        f[K] = aa_gather_general<PRESET, K, PHASE>(g, M, ob, mask, x, y, zl, own, e, U);
+        AaGather<PRESET, PHASE, TUNE, K - 1>::general(g, M, ob, t, lane, x, y, zl, own, e, U, f);
+        f[K] = aa_gather_general<PRESET, K, PHASE>(g, M, ob, t, lane, x, y, zl, own, e, U);
     }
     static __device__ __forceinline__ void store(const Geo& g, float* M, long long own, const float* o) {
         AaGather<PRESET, PHASE, TUNE, K - 1>::store(g, M, own, o);
@@ -403,7 +463,7 @@ struct AaGather {
 template <int PRESET, int PHASE, int TUNE>
 struct AaGather<PRESET, PHASE, TUNE, -1> {
     static __device__ __forceinline__ void fast(const Geo&, const float*, const float*, int, int, int, long long, float, float*) {}
-    static __device__ __forceinline__ void general(const Geo&, const float*, const float*, const unsigned long long*, int, int, int, long long, float, float, float*) {}
+    static __device__ __forceinline__ void general(const Geo&, const float*, const float*, const TileMask&, int, int, int, int, long long, float, float, float*) {}
     static __device__ __forceinline__ void store(const Geo&, float*, long long, const float*) {}
 };
 
@@ -428,14 +488,15 @@ __global__ __launch_bounds__(256) void k_aa_step(
     if (flag == 0) {
         AaGather<PRESET, PHASE, TUNE, Q - 1>::fast(g, M, ob_old, x, y, zl, own, inlet_e, f);
     } else {
-        if (solid_at(g, mask, x, y, zl)) {
+        const TileMask tm = load_tile_mask(g, mask, t.xs, y, zl);
+        if ((tm.w[1][1] >> t.lane) & 1ull) {
             if (want_moments) {
                 rho_out[ridx] = 0.0f;
                 u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             return;
         }
-        AaGather<PRESET, PHASE, TUNE, Q - 1>::general(g, M, ob_old, mask, x, y, zl, own, inlet_e, p.U, f);
+        AaGather<PRESET, PHASE, TUNE, Q - 1>::general(g, M, ob_old, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
     }
     const Moments m = moments_of(f);
     if (want_moments) {
@@ -485,7 +546,7 @@ __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsi
     if (!solid_at(g, prev, x, y, z + 1) || solid_at(g, mask, x, y, z + 1)) return;
     const long long own = cell_off(g, x, y, z + 1);
     for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
         if (phase == 0) M[(long long)k * g.plane + own + d] = weight(k);
         else M[(long long)INV[k] * g.plane + own] = weight(k);
     }
@@ -504,7 +565,7 @@ __global__ void k_aa_export(const float* __restrict__ M, float* __restrict__ den
     const int y = (int)(row - (long long)z * g.H);
     const long long own = cell_off(g, x, y, z + 1);
     for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
         dense[(long long)k * n + i] = phase == 0 ? M[(long long)k * g.plane + own + d] : M[(long long)INV[k] * g.plane + own];
     }
 }
@@ -519,7 +580,7 @@ __global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, flo
     const int y = (int)(row - (long long)z * g.H);
     const long long own = cell_off(g, x, y, z + 1);
     for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.Wp + CX[k];
+        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
         M[(long long)k * g.plane + own + d] = dense[(long long)k * n + i];  // streamed layout
     }
     if (x == g.W - 1)
@@ -535,13 +596,24 @@ __global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, flo
 // ------------------------------------------------------------------------------------------
 // k_init (lbm_solver.cu:37-64): equilibrium at rho = 1, u = 0 is f_k = w_k exactly.  Fills the
 // whole plane (ghost layers and row padding too) of both buffers.
-__global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, long long plane, long long count) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = blockIdx.y;
-    if (i >= count) return;
-    const float w = weight(k);
-    fa[(long long)k * plane + i] = w;
-    fb[(long long)k * plane + i] = w;
+// Every float of the allocation [first, last) relative to plane 0 is filled (ghost layers, row
+// padding, skew and the AA front guard too), with the weight of the population whose run it
+// belongs to.
+__global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, Geo g, int rows_layout,
+                              long long first, long long last) {
+    const long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last) return;
+    long long k;
+    if (rows_layout) {
+        long long r = i % g.row;
+        if (r < 0) r += g.row;
+        k = r / g.Wp;
+    } else {
+        k = i < 0 ? 0 : i / g.plane;
+    }
+    const float w = weight((int)(k < Q ? k : Q - 1));
+    fa[i] = w;
+    fb[i] = w;
 }
 
 __global__ void k_fill_fields(float* __restrict__ rho, float4* __restrict__ u, long long n) {
@@ -673,10 +745,10 @@ __global__ void k_halo_pack(const float* __restrict__ f, float* __restrict__ msg
     const int j = blockIdx.y;
     const int zl = side ? g.D : 1;
     if (j < 5) {
-        if (i < g.layer) msg[(long long)j * g.layer + i] = f[(long long)halo_plane(side, j) * g.plane + (long long)zl * g.layer + i];
+        if (i < g.mlayer) msg[(long long)j * g.mlayer + i] = f[(long long)halo_plane(side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)];
         return;
     }
-    float* tail = msg + 5 * g.layer;
+    float* tail = msg + 5 * g.mlayer;
     if (i >= g.H + 2) return;
     float v = 0.0f;
     if (side) {
@@ -698,10 +770,10 @@ __global__ void k_halo_unpack(float* __restrict__ f, const float* __restrict__ m
     const int zl = side ? g.D + 1 : 0;
     if (j < 5) {
         // the message that arrives on our bottom face is the sender's top message (planes UP5)
-        if (i < g.layer) f[(long long)halo_plane(1 - side, j) * g.plane + (long long)zl * g.layer + i] = msg[(long long)j * g.layer + i];
+        if (i < g.mlayer) f[(long long)halo_plane(1 - side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)] = msg[(long long)j * g.mlayer + i];
         return;
     }
-    const float* tail = msg + 5 * g.layer;
+    const float* tail = msg + 5 * g.mlayer;
     if (side == 0) {
         if (i >= g.H + 2) return;
         if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
@@ -722,10 +794,10 @@ __global__ void k_halo_unpack2(float* __restrict__ f, const float* __restrict__ 
     const int j = blockIdx.y % 6;
     const int zl = side ? g.D + 1 : 0;
     if (j < 5) {
-        if (i < g.layer) f[(long long)halo_plane(1 - side, j) * g.plane + (long long)zl * g.layer + i] = msg[(long long)j * g.layer + i];
+        if (i < g.mlayer) f[(long long)halo_plane(1 - side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)] = msg[(long long)j * g.mlayer + i];
         return;
     }
-    const float* tail = msg + 5 * g.layer;
+    const float* tail = msg + 5 * g.mlayer;
     if (side == 0) {
         if (i >= g.H + 2) return;
         if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
@@ -825,6 +897,9 @@ struct lbm_ctx {
     double last_ms = 0.0;
     uint64_t last_steps = 0;
     size_t pop_bytes = 0;
+    long long pop_floats = 0;  // floats of one population buffer behind f[i]
+    long long guard_floats = 0;  // AA: floats allocated in front of f[0]
+    int layout = LBM_LAYOUT_ROWS;
     std::string err;
 };
 
@@ -1015,12 +1090,35 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     g.Wp = ((aa ? width + 2 : width) + 31) / 32 * 32;  // AA: ghost slots x = -1 and x = W in the row padding
     g.Wm = (width + 63) / 64;
     g.Wt = g.Wm;
-    g.layer = (long long)(aa ? height + 2 : height) * g.Wp;  // AA: ghost rows y = H and y = -1
-    long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 3072) / 4;  // measured best of a 0..1 MiB sweep
-    const long long guard = aa ? g.Wp + 32 : 0;  // AA: (y = -1, z = -1) reaches one row before a plane
-    if (skew_floats < guard) skew_floats = guard;
-    skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
-    g.plane = (long long)(depth + 2) * g.layer + skew_floats;
+    g.mlayer = (long long)height * g.Wp;
+    int layout = o.layout ? o.layout : LBM_LAYOUT_ROWS;  // measured faster, see the note at struct Geo
+    if (const char* t = getenv("LBM_LAYOUT")) layout = atoi(t);
+    if (layout != LBM_LAYOUT_PLANES && layout != LBM_LAYOUT_ROWS) {
+        delete c;
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown layout %d", layout);
+    }
+    c->layout = layout;
+    const long long rows_per_layer = aa ? height + 2 : height;  // AA: ghost rows y = H and y = -1
+    long long guard;                                             // AA: floats in front of plane 0 that (y = -1, z = -1) reaches
+    if (layout == LBM_LAYOUT_ROWS) {
+        long long row_pad = 0;
+        if (const char* t = getenv("LBM_ROW_PAD")) row_pad = atoll(t) / 32 * 32;
+        g.plane = g.Wp;
+        g.row = (long long)Q * g.Wp + (row_pad > 0 ? row_pad : 0);
+        g.layer = rows_per_layer * g.row;
+        guard = aa ? g.row + 32 : 0;
+        c->pop_floats = (long long)(depth + 2) * g.layer;
+    } else {
+        g.row = g.Wp;
+        g.layer = rows_per_layer * g.Wp;
+        long long skew_floats = (o.plane_skew_bytes >= 0 ? o.plane_skew_bytes : 3072) / 4;  // measured best of a 0..1 MiB sweep
+        guard = aa ? g.Wp + 32 : 0;
+        if (skew_floats < guard) skew_floats = guard;
+        skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
+        g.plane = (long long)(depth + 2) * g.layer + skew_floats;
+        c->pop_floats = (long long)Q * g.plane;
+    }
+    c->guard_floats = guard;
     c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
     // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
@@ -1028,7 +1126,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     // in L2 (4.24 vs 5.39 TB/s), so AA keeps nt loads + nt stores + alternating z direction.
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : 7;
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
-    c->pop_bytes = (size_t)Q * g.plane * sizeof(float);
+    c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
     auto cleanup = [&](int code) {
         lbm_destroy(c);
@@ -1090,11 +1188,11 @@ int lbm_destroy(lbm_ctx* c) {
 
 int lbm_init(lbm_ctx* c) {
     NEED(c);
-    // whole plane stride: the AA scheme's ghost slot (y = -1, z = -1) of plane k lies in the skew
-    // region behind plane k-1
-    const long long count = c->g.plane;
-    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(count, 256), Q), dim3(256), 0, c->stream, c->f[0],
-                       c->f[1] ? c->f[1] : c->f[0], c->g.plane, count);
+    // the whole allocation: the AA scheme's ghost slots (y = -1, z = -1) lie in the skew region behind
+    // the previous plane / in the front guard
+    const long long first = -c->guard_floats, last = c->pop_floats;
+    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(last - first, 256)), dim3(256), 0, c->stream, c->f[0],
+                       c->f[1] ? c->f[1] : c->f[0], c->g, c->layout == LBM_LAYOUT_ROWS ? 1 : 0, first, last);
     HIPCHK(c, hipGetLastError());
     if (c->scheme == LBM_SCHEME_AA) {
         const long long per = (long long)c->g.D * c->g.H;
@@ -1302,9 +1400,9 @@ static int copy_populations(lbm_ctx* c, float* host, bool to_host) {
         float* dev = c->f[c->cur] + (long long)k * g.plane + g.layer;  // first owned layer
         float* h = host + (size_t)k * n;
         if (to_host)
-            HIPCHK(c, hipMemcpy2DAsync(h, (size_t)g.W * 4, dev, (size_t)g.Wp * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpy2DAsync(h, (size_t)g.W * 4, dev, (size_t)g.row * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyDeviceToHost, c->stream));
         else
-            HIPCHK(c, hipMemcpy2DAsync(dev, (size_t)g.Wp * 4, h, (size_t)g.W * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpy2DAsync(dev, (size_t)g.row * 4, h, (size_t)g.W * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LBM_OK;
@@ -1439,7 +1537,7 @@ static inline size_t halo_tail_floats(const lbm_ctx* c) { return (size_t)((c->g.
 
 int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
     if (!c || !nfloats) return fail(c, LBM_ERR_INVALID, "lbm_halo_message_floats: null argument");
-    *nfloats = 5 * (size_t)c->g.layer + halo_tail_floats(c);
+    *nfloats = 5 * (size_t)c->g.mlayer + halo_tail_floats(c);
     return LBM_OK;
 }
 
@@ -1455,7 +1553,7 @@ int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
     NEED(c);
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_pack");
     if (rc) return rc;
-    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     // after lbm_step_interior_layers the new state is still f[1-cur] until lbm_step_finish
     const float* src = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
     hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, src, d_message, c->g, side);
@@ -1467,7 +1565,7 @@ int lbm_halo_unpack(lbm_ctx* c, int side, const float* d_message) {
     NEED(c);
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_unpack");
     if (rc) return rc;
-    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
     hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, dst, d_message, c->g, side);
     HIPCHK(c, hipGetLastError());
@@ -1539,7 +1637,7 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
     if (!d_from_below && !d_from_above) return LBM_OK;
     int rc = halo_args_ok(c, 0, d_from_below ? d_from_below : d_from_above, "lbm_halo_unpack_both");
     if (rc) return rc;
-    const long long per = c->g.layer > c->g.H + 2 ? c->g.layer : c->g.H + 2;
+    const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
     hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, c->stream, dst, d_from_below, d_from_above, c->g);
     HIPCHK(c, hipGetLastError());

@@ -15,6 +15,9 @@ PRESET_WIND_TUNNEL = 0
 PRESET_CAVITY = 1
 SCHEME_AB = 0
 SCHEME_AA = 1
+LAYOUT_DEFAULT = 0
+LAYOUT_PLANES = 1
+LAYOUT_ROWS = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
@@ -30,7 +33,7 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("preset", C.c_int32),
                 ("scheme", C.c_int32), ("z0", C.c_int32), ("depth_global", C.c_int32),
                 ("stream", C.c_void_p), ("plane_skew_bytes", C.c_int32),
-                ("reserved0", C.c_int32), ("boundary_stream", C.c_void_p),
+                ("layout", C.c_int32), ("boundary_stream", C.c_void_p),
                 ("reserved", C.c_int32 * 4)]
 
 
@@ -124,7 +127,8 @@ class Solver:
     compute_curl, add_solid, load_mesh, density / velocity / solid-mask read-back, settings."""
 
     def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
-                 stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB, boundary_stream=None):
+                 stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB, boundary_stream=None,
+                 layout=LAYOUT_DEFAULT):
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
@@ -138,6 +142,7 @@ class Solver:
         o.depth_global = depth_global
         o.stream = stream
         o.plane_skew_bytes = plane_skew_bytes
+        o.layout = layout
         o.boundary_stream = boundary_stream
         self._ctx = _ctx()
         rc = self._lib.lbm_create(C.byref(self._ctx), W, H, D, C.byref(o))

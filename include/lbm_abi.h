@@ -59,6 +59,12 @@ enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
  * z-slabs are not supported with AA yet. */
 enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1 };
 
+/* Population storage in HBM (fp32 SoA rows padded to 128-byte lines either way):
+ *   PLANES [k][z][y][x]  19 separate planes, skewed against each other;
+ *   ROWS   [z][y][k][x]  the 19 runs of one (y,z) row interleaved into one contiguous chunk --
+ *                        measured 6-7 % faster under the pull pattern (profiles/r01_tuning.md). */
+enum { LBM_LAYOUT_DEFAULT = 0, LBM_LAYOUT_PLANES = 1, LBM_LAYOUT_ROWS = 2 };
+
 typedef struct lbm_opts {
     int32_t struct_size;   /* = sizeof(lbm_opts); lets the ABI grow */
     int32_t device;        /* HIP device ordinal; -1 = current device */
@@ -69,8 +75,8 @@ typedef struct lbm_opts {
     int32_t z0;
     int32_t depth_global;
     void*   stream;        /* hipStream_t to run on; NULL = the context creates its own */
-    int32_t plane_skew_bytes; /* extra bytes between population planes; -1 = library default */
-    int32_t reserved0;
+    int32_t plane_skew_bytes; /* LBM_LAYOUT_PLANES: extra bytes between population planes; -1 = library default */
+    int32_t layout;        /* LBM_LAYOUT_*; 0 = library default (row-interleaved) */
     /* optional second hipStream_t (ideally high priority) for lbm_step_boundary_layers, so the
      * boundary layers and the halo exchange run beside the interior update instead of in front of
      * it; the CALLER orders the two streams (see cfd_amd/slab.py).  NULL = use `stream`. */

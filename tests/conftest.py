@@ -22,9 +22,11 @@ def oracle():
     return O
 
 
-@pytest.fixture(scope="session")
-def lbm():
-    """The HIP path.  No fallback: a missing library or GPU fails the test."""
+@pytest.fixture(params=["rows", "planes"])
+def lbm(request, monkeypatch):
+    """The HIP path, once per population layout (include/lbm_abi.h LBM_LAYOUT_*; the library reads
+    LBM_LAYOUT at lbm_create).  No fallback: a missing library or GPU fails the test."""
     from cfd_amd import lbm as L
     L.load_library()
+    monkeypatch.setenv("LBM_LAYOUT", str(L.LAYOUT_ROWS if request.param == "rows" else L.LAYOUT_PLANES))
     return L
