@@ -214,8 +214,8 @@ __device__ __forceinline__ float gather_fast(const Geo& g, const float* __restri
         return ldf<TUNE>(row + xs);
     } else {
         const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
-        if (wall) return fin[(long long)INV[K] * g.plane + own];
-        return ldf<TUNE>(row + x - cx);
+        const float* p = wall ? fin + (long long)INV[K] * g.plane + own : row + x - cx;  // one load either way
+        return ldf<TUNE>(p);
     }
 }
 
@@ -1124,7 +1124,9 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
     // In place (AA) the write-through stores lose: partial-line neighbour writes no longer combine
     // in L2 (4.24 vs 5.39 TB/s), so AA keeps nt loads + nt stores + alternating z direction.
-    c->tune = o.scheme == LBM_SCHEME_AA ? 5 : 7;
+    // Row-interleaved A/B (tools/tune_bench.py, 256^3): nt loads + nt stores 6.08 TB/s, with sc1 stores
+    // 5.5, with alternating z 6.03 -> plain nt/nt is the default there.
+    c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
     c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
