@@ -6,10 +6,14 @@
 
 A step is one fused stream-collide update of the whole domain (lbm_step(ctx, 1), 152 algorithmic
 bytes per cell: 19 fp32 populations read + written; rho/u are not written per step).
-N = 1: BASELINE.json configs[1], the 256^3 lid-driven cavity, populations resident in HBM.
-N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) cavity and exchanges
-the five face-crossing populations per face per step with its neighbours by RCCL send/recv
-(torch.distributed backend "nccl"), overlapped with the interior update.
+Default (--config 1): BASELINE.json configs[1], the 256^3 lid-driven cavity, populations resident
+in HBM.  N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) cavity and
+exchanges the five face-crossing populations per face per step with its neighbours by RCCL
+send/recv (torch.distributed backend "nccl"), overlapped with the interior update.
+--config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised
+car stand-in (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
+--config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
+--config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), N = 1 only for now.
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the solver's stream;
 `cpu_baseline` times the CPU oracle (a port of the reference update: the reference has no CPU path)
 on a bounded sample of the same workload, on rank 0 at N = 1 only.
@@ -27,16 +31,19 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_CELL = 152           # 19 populations x 4 B x (read + write)
 
 
-def cpu_baseline(W, H, D, preset, budget_s=12.0):
-    """Oracle (kind "port") on the host cores: same 256^3 cavity state, as many steps as fit the
-    budget (at least 2)."""
+def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
+    """Oracle (kind "port") on the host cores: the same workload, as many steps as fit the budget
+    (at least 2); domains beyond 2^26 cells are cut to their first layers to bound memory and time."""
     from oracle import oracle as O
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     threads = max(1, min(threads, 16))
     os.environ["OMP_NUM_THREADS"] = str(threads)
     O.build()
+    D = max(2, min(D, (1 << 26) // (W * H)))
     s = O.Solver(W, H, D, preset)
     s.init()
+    if obj:
+        s.load_mesh(obj)
     s.step(1)                                   # touch every page
     t0 = time.perf_counter()
     steps = 0
@@ -46,7 +53,7 @@ def cpu_baseline(W, H, D, preset, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": round(W * H * D * steps / dt / 1e6, 2), "unit": "MLUPS", "cores": threads,
             "kind": "port",
-            "sample": f"{W}x{H}x{D} cavity, {steps} steps of oracle/lbm_oracle.c (OpenMP over z, "
+            "sample": f"{W}x{H}x{D} {'cavity' if preset else 'wind tunnel'}{' + car' if obj else ''}, {steps} steps of oracle/lbm_oracle.c (OpenMP over z, "
                       f"{threads} threads, -O2 -ffp-contract=off), {dt:.1f} s"}
 
 
@@ -55,8 +62,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, nargs=3, default=[256, 256, 256], help="per-GPU W H D")
-    ap.add_argument("--preset", choices=["cavity", "wind_tunnel"], default="cavity")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="index into BASELINE.json configs")
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU W H D (overrides the config's size)")
+    ap.add_argument("--preset", choices=["cavity", "wind_tunnel"], default=None)
+    ap.add_argument("--scheme", choices=["ab", "aa"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -73,24 +82,54 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    W, H, D = args.size
-    preset = lbm.PRESET_CAVITY if args.preset == "cavity" else lbm.PRESET_WIND_TUNNEL
+    # per-config workload: (per-GPU size, preset, scheme, obstacle, scaling)
+    cfg = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
+           2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
+           3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
+           4: ((1504, 1536, 1484), "wind_tunnel", "aa", None, "weak")}[args.config]
+    size, preset_name, scheme_name, obstacle, scaling = cfg
+    if args.size:
+        size = tuple(args.size)
+    preset_name = args.preset or preset_name
+    scheme_name = args.scheme or scheme_name
+    W, H, D = size
+    if scaling == "strong":
+        if D % world:
+            raise SystemExit(f"--config {args.config}: depth {D} is not divisible by {world} ranks")
+        Dg, D = D, D // world
+    else:
+        Dg = D * world
+    preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
+    scheme = lbm.SCHEME_AA if scheme_name == "aa" else lbm.SCHEME_AB
+    car = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
     dist = None
     if world > 1:
+        if scheme == lbm.SCHEME_AA:
+            raise SystemExit("z-slabs run the A/B scheme; --scheme aa is single-GPU for now")
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from cfd_amd import slab
-        eng = slab.HipSlabEngine(W, H, D * world, rank * D, D, preset, device=local_rank)
+        eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank)
         solver = eng.solver
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
+        if obstacle:
+            # the host stage of load_mesh on the GLOBAL domain; each rank installs its own layers
+            gmask, _, rc = lbm.host_voxelize_obj(car, W, H, Dg)
+            assert rc == 0
+            solver.set_solid(gmask.reshape(Dg, H * W)[rank * D:(rank + 1) * D])
+            del gmask
         drv.exchange_mask()
         drv.exchange_populations()
         step = drv.step
     else:
-        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank)
+        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, scheme=scheme)
+        if args.config == 4:
+            solver.set_field_window(0, 4)   # sized to HBM: no room for whole-domain rho/u (20 B/cell)
         solver.init()
+        if obstacle:
+            solver.load_mesh(car)
         step = solver.step
 
     def fence():
@@ -113,17 +152,25 @@ def main():
         dt, dev_ms = float(tmax[0]), float(tmax[1])
 
     cells = W * H * D
+    # solid cells are skipped by the kernel (no loads, no stores): the roofline counts fluid cells only
+    fluid = cells
+    if obstacle:
+        fluid = int((solver.solid_mask() == 0).sum())
+        if dist is not None:
+            t = torch.tensor([fluid], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slab with the most fluid sets the step time
+            fluid = int(t[0])
     mlups_total = cells * world * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
     # dominant kernel: k_stream_collide; one launch per step at N=1 (three at N>1: 2 boundary
     # layers + interior); achieved = algorithmic bytes per step / device time per step
     dev_ms_per_step = dev_ms / args.steps
-    achieved = cells * BYTES_PER_CELL / (dev_ms_per_step * 1e-3) / 1e9
+    achieved = fluid * BYTES_PER_CELL / (dev_ms_per_step * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{W}x{H}x{D}_{args.preset}")
+            traffic = json.load(open(tpath)).get(f"{W}x{H}x{D}_{preset_name}_{scheme_name}")
         except Exception:
             traffic = None
 
@@ -133,22 +180,26 @@ def main():
             "value": round(mlups_total, 1), "unit": "MLUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.preset} {W}x{H}x{D * world} D3Q19 fp32, A/B pull, "
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, "
+                                   f"{'AA in-place' if scheme == lbm.SCHEME_AA else 'A/B pull'}, "
+                                   f"{'voxelised car stand-in, ' if obstacle else ''}"
                                    f"{'z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo' if world > 1 else 'one GPU'}"
-                                   " (BASELINE.json configs[1])",
-                       "per_gpu_cells": cells, "bytes_per_cell": BYTES_PER_CELL,
+                                   f" (BASELINE.json configs[{args.config}])",
+                       "per_gpu_cells": cells, "per_gpu_fluid_cells": fluid, "bytes_per_cell": BYTES_PER_CELL,
+                       "layout": "row-interleaved [z][y][k][x], rows padded to 128 B",
                        "moments_per_step": False},
             "mlups_per_gpu": round(mlups_total / world, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "k_stream_collide",
                          "launch_ms": round(dev_ms_per_step, 5),
-                         "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL},
+                         "algorithmic_bytes_per_launch": fluid * BYTES_PER_CELL,
+                         "fluid_cells_per_launch": fluid},
         }
         if world == 1 and not args.no_cpu_baseline:
             solver.close()
-            out["cpu_baseline"] = cpu_baseline(W, H, D, preset)
+            out["cpu_baseline"] = cpu_baseline(W, H, D, preset, car if obstacle else None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

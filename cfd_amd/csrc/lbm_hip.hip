@@ -41,6 +41,7 @@ struct Geo {
     int W, H, D;        // owned extent of this context
     int Dg, z0;         // global depth, global z of owned layer 0
     int slab;           // 1: one z-slab of a taller domain (ghost layers are fed by the halo exchange)
+    int fz0, fnz;       // field window: rho/u are kept for owned layers [fz0, fz0+fnz) only
     int Wp;             // floats per row of one population (multiple of 32: rows start on 128-byte lines)
     int Wm;             // 64-bit mask words per row
     int Wt;             // 64-cell tiles per row (= Wm)
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
     if (x >= g.W) return;
+    if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
 
     const long long own = cell_off(g, x, y, zl);
     const float inlet_e = inlet_bracket(p.U);
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
             // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
             // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
             if (MODE == 1) {
-                const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+                const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
                 rho_out[ridx] = 0.0f;
                 u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
 
     const Moments m = moments_of(f);
     if (MODE == 1) {
-        const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+        const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
         rho_out[ridx] = m.rho;
         u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
         return;
@@ -481,8 +483,10 @@ __global__ __launch_bounds__(256) void k_aa_step(
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
     if (x >= g.W) return;
+    if (flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
     const long long own = cell_off(g, x, y, zl);
-    const long long ridx = ((long long)(zl - 1) * g.H + y) * g.W + x;
+    const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
+    want_moments = want_moments && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
     const float inlet_e = inlet_bracket(p.U);
     float f[Q];
     if (flag == 0) {
@@ -669,7 +673,7 @@ __global__ void k_add_rect(unsigned long long* __restrict__ mask, Geo g, int rx,
     mask[wi] |= bits;
 }
 
-// per-tile path flag: 0 = interior fast path, 1 = full boundary chain
+// per-tile path flag: 0 = interior fast path, 1 = full boundary chain, 2 = every cell solid (skipped)
 template <int PRESET>
 __global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ flags, Geo g) {
     const long long ti = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -681,7 +685,11 @@ __global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsign
     const int y = (int)(row - (long long)z * g.H);
     const int zg = z + g.z0;
     unsigned char fl = 0;
-    if (y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1) {
+    const int cnt = min(64, g.W - xs * 64);
+    const unsigned long long all = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    if ((mask[((long long)(z + 1) * g.H + y) * g.Wm + xs] & all) == all) {
+        fl = 2;
+    } else if (y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1) {
         fl = 1;
     } else {
         unsigned long long any = 0;
@@ -931,10 +939,12 @@ static int fail(lbm_ctx* c, int code, const char* fmt, ...) {
     } while (0)
 
 static inline long long cells(const lbm_ctx* c) { return (long long)c->g.W * c->g.H * c->g.D; }
+static inline long long field_cells(const lbm_ctx* c) { return (long long)c->g.W * c->g.H * c->g.fnz; }
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 static int ensure_field_buffers(lbm_ctx* c) {
-    const long long n = cells(c);
+    const long long n = field_cells(c);
+    if (n == 0) return LBM_OK;
     if (!c->rho) HIPCHK(c, hipMalloc(&c->rho, n * sizeof(float)));
     if (!c->u) HIPCHK(c, hipMalloc(&c->u, n * sizeof(float4)));
     return LBM_OK;
@@ -1023,16 +1033,19 @@ static int launch_aa_step(lbm_ctx* c, int want_moments) {
 
 // bring rho/u up to date: what the reference's per-step writes would hold right now
 static int materialise_fields(lbm_ctx* c) {
+    if (c->g.fnz == 0) return fail(c, LBM_ERR_STATE, "the field window is empty (lbm_set_field_window)");
     if (c->fields == FIELDS_VALID) return LBM_OK;
     int rc = ensure_field_buffers(c);
     if (rc) return rc;
     if (c->fields == FIELDS_INIT) {
-        hipLaunchKernelGGL(k_fill_fields, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->rho, c->u, cells(c));
+        hipLaunchKernelGGL(k_fill_fields, dim3(blocks_for(field_cells(c), 256)), dim3(256), 0, c->stream, c->rho, c->u, field_cells(c));
         HIPCHK(c, hipGetLastError());
+    } else if (c->scheme == LBM_SCHEME_AA) {
+        return fail(c, LBM_ERR_STATE, "AA scheme: rho/u of a new field window exist after the next lbm_step()");
     } else {
         // the last step read f[1-cur]; it is still intact (A/B), so the same gather gives the
         // same post-stream moments (lbm_solver.cu:320-337)
-        rc = launch_stream_collide<1>(c, c->f[1 - c->cur], nullptr, c->p_last, 1, c->g.D);
+        rc = launch_stream_collide<1>(c, c->f[1 - c->cur], nullptr, c->p_last, 1 + c->g.fz0, c->g.fnz);
         if (rc) return rc;
     }
     c->fields = FIELDS_VALID;
@@ -1085,6 +1098,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     Geo& g = c->g;
     g.W = width; g.H = height; g.D = depth; g.Dg = Dg; g.z0 = z0;
     g.slab = o.depth_global > 0 ? 1 : 0;
+    g.fz0 = 0; g.fnz = depth;
     c->scheme = o.scheme;
     const bool aa = o.scheme == LBM_SCHEME_AA;
     g.Wp = ((aa ? width + 2 : width) + 31) / 32 * 32;  // AA: ghost slots x = -1 and x = W in the row padding
@@ -1288,7 +1302,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         // in place there is no previous buffer to recompute rho/u from: the last step of the batch
         // writes them (20 B/cell once per call)
         rc = ensure_field_buffers(c);
-        for (int s = 0; s < nsteps && !rc; s++) rc = launch_aa_step(c, s == nsteps - 1);
+        for (int s = 0; s < nsteps && !rc; s++) rc = launch_aa_step(c, s == nsteps - 1 && c->g.fnz > 0);
         if (rc) return rc;
         c->p_last = c->p;
         c->steps += (uint64_t)nsteps;
@@ -1316,11 +1330,27 @@ int lbm_compute_curl(lbm_ctx* c) {
     rc = materialise_fields(c);
     if (rc) return rc;
     if (c->curl_valid) return LBM_OK;
+    if (c->g.fnz != c->g.D)
+        return fail(c, LBM_ERR_STATE, "lbm_compute_curl: the curl's z differences need the whole domain in the field window");
     if (!c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
     dim3 grid((c->g.W + 255) / 256, c->g.H, c->g.D);
     hipLaunchKernelGGL(k_curl, grid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
     HIPCHK(c, hipGetLastError());
     c->curl_valid = true;
+    return LBM_OK;
+}
+
+int lbm_set_field_window(lbm_ctx* c, int z_begin, int nz) {
+    NEED(c);
+    if (z_begin < 0 || nz < 0 || (long long)z_begin + nz > c->g.D)
+        return fail(c, LBM_ERR_INVALID, "lbm_set_field_window: [%d, %d+%d) outside the %d owned layers", z_begin, z_begin, nz, c->g.D);
+    if (z_begin == c->g.fz0 && nz == c->g.fnz) return LBM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->rho); (void)hipFree(c->u); (void)hipFree(c->curl);
+    c->rho = nullptr; c->u = nullptr; c->curl = nullptr;
+    c->g.fz0 = z_begin; c->g.fnz = nz;
+    if (c->fields == FIELDS_VALID) c->fields = FIELDS_STALE;  // A/B: recomputed on demand; AA: after the next step
+    c->curl_valid = false;
     return LBM_OK;
 }
 
@@ -1338,7 +1368,7 @@ static int read_back(lbm_ctx* c, void* dst, const void* src, size_t bytes) {
 
 int lbm_read_density(lbm_ctx* c, float* rho, size_t n) {
     NEED(c);
-    if (!rho || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_density: need %lld floats", cells(c));
+    if (!rho || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_density: need %lld floats", field_cells(c));
     int rc = refresh_mask_state(c);
     if (!rc) rc = materialise_fields(c);
     if (rc) return rc;
@@ -1347,7 +1377,7 @@ int lbm_read_density(lbm_ctx* c, float* rho, size_t n) {
 
 int lbm_read_velocity(lbm_ctx* c, float* u, size_t n) {
     NEED(c);
-    if (!u || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity: need %lld x 4 floats", cells(c));
+    if (!u || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity: need %lld x 4 floats", field_cells(c));
     int rc = refresh_mask_state(c);
     if (!rc) rc = materialise_fields(c);
     if (rc) return rc;
@@ -1461,7 +1491,13 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
 
 int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, uint8_t** d_solid) {
     NEED(c);
-    int rc = lbm_compute_curl(c);
+    int rc;
+    if (c->g.fnz == c->g.D) {
+        rc = lbm_compute_curl(c);
+    } else {  // partial field window: rho/u of the window only, no curl
+        rc = refresh_mask_state(c);
+        if (!rc) rc = materialise_fields(c);
+    }
     if (rc) return rc;
     if (d_solid) {  // dense copy of the bit-packed mask in the reference's wire format
         const long long n = cells(c);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lbm_step": ([_ctx, C.c_int], C.c_int),
     "lbm_compute_curl": ([_ctx], C.c_int),
     "lbm_sync": ([_ctx], C.c_int),
+    "lbm_set_field_window": ([_ctx, C.c_int, C.c_int], C.c_int),
     "lbm_read_density": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_velocity": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
@@ -132,6 +133,7 @@ class Solver:
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
+        self.nf = self.n          # cells inside the field window
         self.preset = preset
         o = Opts()
         o.struct_size = C.sizeof(Opts)
@@ -205,14 +207,18 @@ class Solver:
     def sync(self):
         self._chk(self._lib.lbm_sync(self._ctx))
 
+    def set_field_window(self, z_begin, nz):
+        self._chk(self._lib.lbm_set_field_window(self._ctx, z_begin, nz))
+        self.nf = self.W * self.H * nz
+
     def density(self):
-        out = np.empty(self.n, np.float32)
+        out = np.empty(self.nf, np.float32)
         self._chk(self._lib.lbm_read_density(self._ctx, _f(out), out.size))
         return out
 
     def velocity(self):
-        out = np.empty((self.n, 4), np.float32)
-        self._chk(self._lib.lbm_read_velocity(self._ctx, _f(out), self.n))
+        out = np.empty((self.nf, 4), np.float32)
+        self._chk(self._lib.lbm_read_velocity(self._ctx, _f(out), self.nf))
         return out
 
     def solid_mask(self):

@@ -149,6 +149,16 @@ int lbm_read_classification(lbm_ctx* ctx, uint8_t* cls, size_t n_times_19);
  * Any output pointer may be NULL.  d_solid is a dense uint8 copy (0/255) of the packed mask. */
 int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_curl, uint8_t** d_solid);
 
+/* Domains sized to HBM (BASELINE.json configs[4]: 266 GB of populations on a 288 GB GPU) have
+ * no room for whole-domain rho/u (20 B/cell, where the reference allocates them up front,
+ * lbm_solver.cu:410-411).  The field window restricts rho/u to the owned layers
+ * [z_begin, z_begin+nz): lbm_read_density / lbm_read_velocity / lbm_device_fields then take and
+ * return W*H*nz elements, so a caller can walk the domain window by window (A/B scheme: any
+ * window of the last step is materialised on demand; AA scheme: the window is filled by the next
+ * lbm_step).  nz = 0 keeps no fields at all; the default is the whole domain.  lbm_compute_curl
+ * needs the whole domain in the window.  No counterpart in the reference. */
+int lbm_set_field_window(lbm_ctx* ctx, int z_begin, int nz);
+
 int lbm_get_dims(lbm_ctx* ctx, int* w, int* h, int* d);
 int lbm_get_stats(lbm_ctx* ctx, lbm_stats* out);
 int lbm_timer_begin(lbm_ctx* ctx);

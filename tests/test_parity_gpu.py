@@ -177,3 +177,35 @@ def test_against_committed_golden_fingerprints(lbm):
     for case in make_golden.CASES:
         got = make_golden.run_case(lbm.Solver, *case, GOLDEN)
         assert got == gold[case[0]], case[0]
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_field_window(oracle, lbm, scheme):
+    """lbm_set_field_window: rho/u restricted to a z range (domains sized to HBM have no room for
+    whole-domain fields); every window equals the same layers of the oracle's fields."""
+    W, H, D = 70, 12, 20
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D, scheme=scheme)
+    for s in (o, g):
+        s.init(); s.add_solid(20, 0, 5, 9, 7, 11)
+    g.set_field_window(6, 5)
+    o.step(7); g.step(7)
+    ro = o.density().reshape(D, H * W); uo = o.velocity().reshape(D, H * W, 4)
+    np.testing.assert_array_equal(g.density().reshape(5, -1), ro[6:11])
+    np.testing.assert_array_equal(g.velocity().reshape(5, -1, 4), uo[6:11])
+    with pytest.raises(lbm.LbmError):
+        g.curl_field()                                  # z differences need the whole domain
+    if scheme == 0:                                     # A/B: any other window of the same step on demand
+        g.set_field_window(0, 3)
+        np.testing.assert_array_equal(g.density().reshape(3, -1), ro[0:3])
+    g.set_field_window(17, 3)
+    o.step(2); g.step(2)
+    np.testing.assert_array_equal(g.density().reshape(3, -1), o.density().reshape(D, -1)[17:20])
+    g.set_field_window(0, 0)
+    g.step(3); o.step(3)                                # no fields kept at all
+    with pytest.raises(lbm.LbmError):
+        g.density()
+    g.set_field_window(0, D)
+    o.step(1); g.step(1)
+    np.testing.assert_array_equal(g.density(), o.density())
+    np.testing.assert_array_equal(g.curl_field(), (o.compute_curl(), o.curl_field())[1])
