@@ -13,7 +13,7 @@ send/recv (torch.distributed backend "nccl"), overlapped with the interior updat
 --config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised
 car stand-in (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
 --config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
---config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), N = 1 only for now.
+--config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), weak scaling over z-slabs.
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the solver's stream;
 `cpu_baseline` times the CPU oracle (a port of the reference update: the reference has no CPU path)
 on a bounded sample of the same workload, on rank 0 at N = 1 only.
@@ -105,13 +105,13 @@ def main():
 
     dist = None
     if world > 1:
-        if scheme == lbm.SCHEME_AA:
-            raise SystemExit("z-slabs run the A/B scheme; --scheme aa is single-GPU for now")
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from cfd_amd import slab
-        eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank)
+        eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme)
         solver = eng.solver
+        if args.config == 4:
+            solver.set_field_window(0, 4)
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
         if obstacle:

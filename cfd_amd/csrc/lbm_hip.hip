@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256) void k_stream_collide(
 constexpr int OB_N = 7;
 constexpr int OB_PLANE[OB_N] = {2, 8, 9, 10, 12, 13, 14};
 __host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <= 10 ? pl - 7 : pl - 8); }
+// side-array slot of plane-slot i, local layer z in [-1, D] (ghost rows for the z-slab halo), row y
+__device__ __forceinline__ long long ob_at(const Geo& g, int i, int z, int y) {
+    return ((long long)i * (g.D + 2) + (z + 1)) * g.H + y;
+}
 
 template <int K>
 __device__ __forceinline__ long long dir_off(const Geo& g) {
@@ -399,9 +403,12 @@ __device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __res
     int nz = (zl - 1) - CZ[K];
     if (ny < 0) { ny += g.H; nz -= 1; }
     else if (ny >= g.H) { ny -= g.H; nz += 1; }
-    if (nz < 0) { nz += g.D; pl -= 1; }
-    else if (nz >= g.D) { nz -= g.D; pl += 1; }
-    return ob_old[((long long)ob_index(pl) * g.D + nz) * g.H + ny];
+    // as outlet_off(): an undecomposed domain wraps to its own far layer, a slab finds the
+    // neighbour's (or, over the ring link, the far rank's) column in its ghost row
+    const int nzg = nz + g.z0;
+    if (nzg < 0) { pl -= 1; if (!g.slab) nz += g.D; }
+    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nz -= g.D; }
+    return ob_old[ob_at(g, ob_index(pl), nz, ny)];
 }
 
 template <int PRESET, int K, int PHASE>
@@ -433,7 +440,7 @@ __device__ __forceinline__ float aa_gather_fast(const Geo& g, const float* M, co
             return x == 0 ? weight(K) * inlet_e : v;
         }
         if (x == g.W - 1)  // interior tile: ny, nz are in range
-            return ob_old[((long long)ob_index(K) * g.D + (zl - 1 - CZ[K])) * g.H + (y - CY[K])];
+            return ob_old[ob_at(g, ob_index(K), zl - 1 - CZ[K], y - CY[K])];
         return ldf<TUNE>(p);
     } else {
         const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
@@ -475,10 +482,12 @@ __global__ __launch_bounds__(256) void k_aa_step(
     float* M, const float* __restrict__ ob_old, float* __restrict__ ob_new,
     const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
     float* __restrict__ rho_out, float4* __restrict__ u_out, Geo g, Params p, int segsx_log2, int zrev,
-    int want_moments) {
+    int want_moments, int zl_begin, int zl_second) {
     const TileId t = tile_of_wave(segsx_log2);
     const int y = t.y;
-    const int zl = 1 + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    // zl_second > 0: the two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
+    const int zl = zl_second > 0 ? (blockIdx.z == 0 ? zl_begin : zl_second)
+                                 : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
@@ -511,9 +520,8 @@ __global__ __launch_bounds__(256) void k_aa_step(
     collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
     AaGather<PRESET, PHASE, TUNE, Q - 1>::store(g, M, own, o);
     if (x == g.W - 1) {
-        const long long col = (long long)(zl - 1) * g.H + y;
 #pragma unroll
-        for (int i = 0; i < OB_N; i++) ob_new[(long long)i * g.D * g.H + col] = o[OB_PLANE[i]];
+        for (int i = 0; i < OB_N; i++) ob_new[ob_at(g, i, zl - 1, y)] = o[OB_PLANE[i]];
     }
 }
 
@@ -532,7 +540,7 @@ __global__ void k_ob_sync(const float* __restrict__ cur, float* __restrict__ oth
     if (col >= (long long)g.D * g.H) return;
     const int z = (int)(col / g.H), y = (int)(col - (long long)z * g.H);
     if (!solid_at(g, mask, g.W - 1, y, z + 1)) return;
-    for (int i = 0; i < OB_N; i++) other[(long long)i * g.D * g.H + col] = cur[(long long)i * g.D * g.H + col];
+    for (int i = 0; i < OB_N; i++) other[ob_at(g, i, z, y)] = cur[ob_at(g, i, z, y)];
 }
 
 // A cell that the new mask turns from solid to fluid restarts from equilibrium (F_k = w_k): the
@@ -555,7 +563,7 @@ __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsi
         else M[(long long)INV[k] * g.plane + own] = weight(k);
     }
     if (x == g.W - 1)
-        for (int j = 0; j < OB_N; j++) ob_cur[(long long)j * g.D * g.H + (long long)z * g.H + y] = weight(OB_PLANE[j]);
+        for (int j = 0; j < OB_N; j++) ob_cur[ob_at(g, j, z, y)] = weight(OB_PLANE[j]);
 }
 
 // canonical f[k*n + idx] <-> the in-place layout of the moment
@@ -590,8 +598,8 @@ __global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, flo
     if (x == g.W - 1)
         for (int j = 0; j < OB_N; j++) {
             const float v = dense[(long long)OB_PLANE[j] * n + i];
-            ob_a[(long long)j * g.D * g.H + (long long)z * g.H + y] = v;
-            ob_b[(long long)j * g.D * g.H + (long long)z * g.H + y] = v;
+            ob_a[ob_at(g, j, z, y)] = v;
+            ob_b[ob_at(g, j, z, y)] = v;
         }
 }
 
@@ -817,6 +825,54 @@ __global__ void k_halo_unpack2(float* __restrict__ f, const float* __restrict__ 
     }
 }
 
+// ---- AA z-slab halo ---------------------------------------------------------------------------
+// Which slots carry the five populations that cross a face depends on the layout of the moment:
+//   swapped  (after an EVEN step): F_k of a boundary-layer cell sits in the OWNED layer at plane
+//            inv(k); it goes to the same plane of the neighbour's GHOST layer, where the
+//            neighbour's odd step pulls it from;
+//   streamed (after an ODD step, or after init / import): the cell has pushed F_k into OUR GHOST
+//            layer at plane k; it goes to the neighbour's OWNED boundary layer, same plane, where
+//            the neighbour's even step reads its own slots.
+// Only cells x < W, 0 <= y < H travel: the x/y ghost shell of a layer belongs to the wall logic of
+// the slab that wrote it.  Message = 5 layers of H*Wp floats + the 7 outlet-column planes of the
+// boundary layer (7*H floats, what aa_outlet_read needs across the face, ring link included).
+__global__ void k_aa_halo_pack(const float* __restrict__ M, const float* __restrict__ ob, float* __restrict__ msg,
+                               Geo g, int side, int streamed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (j < 5) {
+        if (i >= g.mlayer) return;
+        const int x = (int)(i % g.Wp), y = (int)(i / g.Wp);
+        if (x >= g.W) return;
+        const int zl = streamed ? (side ? g.D + 1 : 0) : (side ? g.D : 1);
+        const int pl = streamed ? (side ? UP5[j] : DOWN5[j]) : (side ? DOWN5[j] : UP5[j]);
+        msg[(long long)j * g.mlayer + i] = M[(long long)pl * g.plane + cell_off(g, x, y, zl)];
+        return;
+    }
+    if (i >= (long long)OB_N * g.H) return;
+    msg[5 * g.mlayer + i] = ob[ob_at(g, (int)(i / g.H), side ? g.D - 1 : 0, (int)(i % g.H))];
+}
+// side: the face of THIS slab the message arrived on (0: from the lower neighbour's top face)
+__global__ void k_aa_halo_unpack(float* __restrict__ M, float* __restrict__ ob, const float* __restrict__ msg,
+                                 Geo g, int side, int streamed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (j < 5) {
+        if (i >= g.mlayer) return;
+        // the ring link of the wind-tunnel preset carries only the outlet column: beyond a domain end
+        // there is no cell, and the ghost slots there belong to this slab's own wall logic
+        if (side ? (g.z0 + g.D == g.Dg) : (g.z0 == 0)) return;
+        const int x = (int)(i % g.Wp), y = (int)(i / g.Wp);
+        if (x >= g.W) return;
+        const int zl = streamed ? (side ? g.D : 1) : (side ? g.D + 1 : 0);
+        const int pl = streamed ? (side ? DOWN5[j] : UP5[j]) : (side ? UP5[j] : DOWN5[j]);
+        M[(long long)pl * g.plane + cell_off(g, x, y, zl)] = msg[(long long)j * g.mlayer + i];
+        return;
+    }
+    if (i >= (long long)OB_N * g.H) return;
+    ob[ob_at(g, (int)(i / g.H), side ? g.D : -1, (int)(i % g.H))] = msg[5 * g.mlayer + i];
+}
+
 // one layer of the packed mask <-> dense u8 (ghost exchange of the static mask)
 __global__ void k_mask_layer_get(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g, int zl) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1002,14 +1058,17 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     return LBM_OK;
 }
 
-static int launch_aa_step(lbm_ctx* c, int want_moments) {
+// one AA launch over layers [zl_begin, zl_begin + nlayers), or over the two layers zl_begin and
+// zl_second when zl_second > 0; the caller flips the phase with aa_flip() once the step is complete
+static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, int zl_second) {
+    if (nlayers <= 0) return LBM_OK;
     const int segsx = 1 << c->segsx_log2;
-    dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), c->g.D);
-    const int zrev = (c->tune & 4) ? c->zrev : 0;
+    dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
+    const int zrev = ((c->tune & 4) && nlayers == c->g.D) ? c->zrev : 0;
 #define LBM_AA(PRESET, PHASE, TUNE)                                                                               \
     hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, c->stream, c->f[0], c->ob[c->ob_cur],  \
                        c->ob[1 - c->ob_cur], c->mask, c->flags, c->rho, c->u, c->g, c->p, c->segsx_log2, zrev,     \
-                       want_moments)
+                       want_moments, zl_begin, zl_second)
 #define LBM_AA_T(PRESET, PHASE)                       \
     switch (c->tune & 3) {                            \
         case 0: LBM_AA(PRESET, PHASE, 0); break;      \
@@ -1025,10 +1084,17 @@ static int launch_aa_step(lbm_ctx* c, int want_moments) {
 #undef LBM_AA_T
 #undef LBM_AA
     HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+static void aa_flip(lbm_ctx* c) {
     c->aa_phase ^= 1;
     c->ob_cur ^= 1;
     c->zrev ^= 1;
-    return LBM_OK;
+}
+static int launch_aa_step(lbm_ctx* c, int want_moments) {
+    int rc = launch_aa(c, want_moments, 1, c->g.D, 0);
+    if (!rc) aa_flip(c);
+    return rc;
 }
 
 // bring rho/u up to date: what the reference's per-step writes would hold right now
@@ -1077,8 +1143,6 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown preset %d", o.preset);
     if (o.scheme != LBM_SCHEME_AB && o.scheme != LBM_SCHEME_AA)
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
-    if (o.scheme == LBM_SCHEME_AA && o.depth_global > 0)
-        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: the AA scheme does not support z-slabs yet (use LBM_SCHEME_AB)");
     int Dg = o.depth_global > 0 ? o.depth_global : depth;
     int z0 = o.depth_global > 0 ? o.z0 : 0;
     if (z0 < 0 || (long long)z0 + depth > Dg)
@@ -1168,7 +1232,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     if (aa) {
         CR(hipMalloc(&c->alloc0, c->pop_bytes + (size_t)guard * sizeof(float)));
         c->f[0] = c->alloc0 + guard;
-        const size_t ob_bytes = (size_t)OB_N * depth * height * sizeof(float);
+        const size_t ob_bytes = (size_t)OB_N * (depth + 2) * height * sizeof(float);
         CR(hipMalloc(&c->ob[0], ob_bytes));
         CR(hipMalloc(&c->ob[1], ob_bytes));
         CR(hipMalloc(&c->prev_mask, mask_bytes));
@@ -1211,7 +1275,7 @@ int lbm_init(lbm_ctx* c) {
                        c->f[1] ? c->f[1] : c->f[0], c->g, c->layout == LBM_LAYOUT_ROWS ? 1 : 0, first, last);
     HIPCHK(c, hipGetLastError());
     if (c->scheme == LBM_SCHEME_AA) {
-        const long long per = (long long)c->g.D * c->g.H;
+        const long long per = (long long)(c->g.D + 2) * c->g.H;
         hipLaunchKernelGGL(k_ob_fill, dim3(blocks_for(per * OB_N, 256)), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
         HIPCHK(c, hipGetLastError());
         c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
@@ -1571,7 +1635,22 @@ int lbm_host_collide_cell(const float* f19, float omega_shear, float omega_bulk,
 }
 
 // ---- z-slab API ---------------------------------------------------------------------------
-static inline size_t halo_tail_floats(const lbm_ctx* c) { return (size_t)((c->g.H + 2 + 31) / 32 * 32); }
+static inline size_t halo_tail_floats(const lbm_ctx* c) {
+    const size_t n = c->scheme == LBM_SCHEME_AA ? (size_t)OB_N * c->g.H : (size_t)c->g.H + 2;
+    return (n + 31) / 32 * 32;
+}
+// AA: is the buffer in the streamed layout once the step in flight (if any) is complete?
+static inline int aa_streamed_now(const lbm_ctx* c) { return (c->split_phase ? c->aa_phase ^ 1 : c->aa_phase) == 0; }
+static inline float* aa_newest_ob(lbm_ctx* c) { return c->split_phase ? c->ob[1 - c->ob_cur] : c->ob[c->ob_cur]; }
+static int aa_halo(lbm_ctx* c, int side, float* msg, bool pack) {
+    const long long per = c->g.mlayer > (long long)OB_N * c->g.H ? c->g.mlayer : (long long)OB_N * c->g.H;
+    if (pack)
+        hipLaunchKernelGGL(k_aa_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
+    else
+        hipLaunchKernelGGL(k_aa_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
 
 int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
     if (!c || !nfloats) return fail(c, LBM_ERR_INVALID, "lbm_halo_message_floats: null argument");
@@ -1580,7 +1659,6 @@ int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
 }
 
 static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
-    if (c->scheme != LBM_SCHEME_AB) return fail(c, LBM_ERR_STATE, "%s: z-slabs need LBM_SCHEME_AB", who);
     if (!c->g.slab) return fail(c, LBM_ERR_STATE, "%s: context was not created as a slab (lbm_opts.depth_global = 0)", who);
     if (side != 0 && side != 1) return fail(c, LBM_ERR_INVALID, "%s: side must be 0 or 1", who);
     if (!p) return fail(c, LBM_ERR_INVALID, "%s: buffer is null", who);
@@ -1591,6 +1669,7 @@ int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
     NEED(c);
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_pack");
     if (rc) return rc;
+    if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, d_message, true);
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     // after lbm_step_interior_layers the new state is still f[1-cur] until lbm_step_finish
     const float* src = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
@@ -1603,6 +1682,7 @@ int lbm_halo_unpack(lbm_ctx* c, int side, const float* d_message) {
     NEED(c);
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_unpack");
     if (rc) return rc;
+    if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, const_cast<float*>(d_message), false);
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
     hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, dst, d_message, c->g, side);
@@ -1651,7 +1731,6 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
 
 int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
     NEED(c);
-    if (c->scheme != LBM_SCHEME_AB) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: z-slabs need LBM_SCHEME_AB");
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
     if ((d_msg_bottom || d_msg_top) && !c->g.slab)
         return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: messages need a slab context");
@@ -1661,6 +1740,17 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
     if (was_dirty && c->stream_b) {  // the set-up kernels ran on the main stream: order the side stream behind them
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev1, 0));
+    }
+    if (c->scheme == LBM_SCHEME_AA) {
+        // in place: the boundary layers, then two small pack launches (the layout of the moment decides
+        // which slots travel, see k_aa_halo_pack); rho/u are written when the field window is not empty
+        rc = ensure_field_buffers(c);
+        if (!rc) rc = launch_aa(c, c->g.fnz > 0, 1, c->g.D > 1 ? 2 : 1, c->g.D);
+        if (rc) return rc;
+        c->split_phase = 1;
+        if (d_msg_bottom) rc = aa_halo(c, 0, d_msg_bottom, true);
+        if (!rc && d_msg_top) rc = aa_halo(c, 1, d_msg_top, true);
+        return rc;
     }
     // one launch for both boundary layers; it writes the outgoing messages as it goes
     rc = launch_stream_collide<2>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D > 1 ? 2 : 1, c->g.D,
@@ -1675,6 +1765,11 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
     if (!d_from_below && !d_from_above) return LBM_OK;
     int rc = halo_args_ok(c, 0, d_from_below ? d_from_below : d_from_above, "lbm_halo_unpack_both");
     if (rc) return rc;
+    if (c->scheme == LBM_SCHEME_AA) {
+        if (d_from_below) rc = aa_halo(c, 0, const_cast<float*>(d_from_below), false);
+        if (!rc && d_from_above) rc = aa_halo(c, 1, const_cast<float*>(d_from_above), false);
+        return rc;
+    }
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
     hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, c->stream, dst, d_from_below, d_from_above, c->g);
@@ -1685,7 +1780,8 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
 int lbm_step_interior_layers(lbm_ctx* c) {
     NEED(c);
     if (c->split_phase != 1) return fail(c, LBM_ERR_STATE, "lbm_step_interior_layers: call lbm_step_boundary_layers first");
-    int rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 2, c->g.D - 2);
+    int rc = c->scheme == LBM_SCHEME_AA ? launch_aa(c, c->g.fnz > 0, 2, c->g.D - 2, 0)
+                                        : launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 2, c->g.D - 2);
     if (rc) return rc;
     c->split_phase = 2;
     return LBM_OK;
@@ -1694,10 +1790,11 @@ int lbm_step_interior_layers(lbm_ctx* c) {
 int lbm_step_finish(lbm_ctx* c) {
     NEED(c);
     if (c->split_phase != 2) return fail(c, LBM_ERR_STATE, "lbm_step_finish: call lbm_step_interior_layers first");
-    c->cur = 1 - c->cur;
+    if (c->scheme == LBM_SCHEME_AA) aa_flip(c);
+    else c->cur = 1 - c->cur;
     c->p_last = c->p;
     c->steps += 1;
-    c->fields = FIELDS_STALE;
+    c->fields = c->scheme == LBM_SCHEME_AA ? FIELDS_VALID : FIELDS_STALE;
     c->curl_valid = false;
     c->split_phase = 0;
     return LBM_OK;

@@ -43,7 +43,7 @@ def neighbours(preset, world, rank):
 class HipSlabEngine:
     """One HIP context owning global layers [z0, z0+D)."""
 
-    def __init__(self, W, H, depth_global, z0, D, preset, device=-1, two_streams=False):
+    def __init__(self, W, H, depth_global, z0, D, preset, device=-1, two_streams=False, scheme=lbm.SCHEME_AB):
         self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
         # The context runs on torch streams of its own (non-null handles: handing over the legacy
         # default stream, handle 0, would make the library create a private stream that
@@ -58,7 +58,7 @@ class HipSlabEngine:
         if two_streams:
             self.bstream = torch.cuda.Stream(device=self.device, priority=-1 if mode == "2p" else 0)
         self.solver = lbm.Solver(W, H, D, preset=preset, device=self.device.index, z0=z0,
-                                 depth_global=depth_global, stream=self.stream.cuda_stream,
+                                 depth_global=depth_global, stream=self.stream.cuda_stream, scheme=scheme,
                                  boundary_stream=self.bstream.cuda_stream if two_streams else None)
         self._lib = self.solver._lib
         self._ctx = self.solver._ctx

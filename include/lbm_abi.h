@@ -55,8 +55,8 @@ enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
  * buffer updated in place (even step: own cell read / swapped own cell write; odd step:
  * neighbour read / neighbour write): same results, half the population memory; rho/u are written
  * by the last step of each lbm_step() call; a cell that a later mask change turns from solid back
- * to fluid restarts from equilibrium (there is no second buffer to keep its frozen values);
- * z-slabs are not supported with AA yet. */
+ * to fluid restarts from equilibrium (there is no second buffer to keep its frozen values).
+ * Both schemes run as z-slabs. */
 enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1 };
 
 /* Population storage in HBM (fp32 SoA rows padded to 128-byte lines either way):
@@ -194,7 +194,11 @@ int lbm_host_collide_cell(const float* f19, float omega_shear, float omega_bulk,
  * of lbm_halo_message_floats() floats; lbm_halo_unpack scatters the message received from the
  * neighbour on `side` into that side's ghost layer.  The transport in between is the caller's
  * (RCCL send/recv via torch.distributed in cfd_amd/slab.py; a device copy in single-GPU tests).
- * Both run on the context's stream. */
+ * Both run on the context's stream.
+ * With LBM_SCHEME_AA the same calls apply; what a message carries follows the layout of the moment
+ * (after an even step the boundary layer's own slots go to the neighbour's ghost layer, after an odd
+ * step the values pushed into the ghost layer go to the neighbour's boundary layer) and its tail is
+ * the outlet-column side array of the boundary layer (7*H floats). */
 int lbm_halo_message_floats(lbm_ctx* ctx, size_t* nfloats);
 int lbm_halo_pack(lbm_ctx* ctx, int side, float* d_message);
 int lbm_halo_unpack(lbm_ctx* ctx, int side, const float* d_message);

@@ -95,5 +95,3 @@ def test_aa_equals_ab_and_halves_memory(lbm):
     np.testing.assert_array_equal(a.density(), b.density())
     np.testing.assert_array_equal(a.velocity(), b.velocity())
     assert b.stats()["population_bytes"] < 0.7 * a.stats()["population_bytes"]   # one buffer + ghost shell padding
-    with pytest.raises(lbm.LbmError):
-        lbm.Solver(16, 16, 8, scheme=lbm.SCHEME_AA, z0=0, depth_global=16)

@@ -10,11 +10,11 @@ from conftest import CUBE_OBJ
 pytestmark = pytest.mark.gpu
 
 
-def run_slabs(lbm, W, H, Dg, preset, splits, mask, steps, params=None):
+def run_slabs(lbm, W, H, Dg, preset, splits, mask, steps, params=None, scheme=0):
     from cfd_amd import slab
     engines, z0 = [], 0
     for d in splits:
-        engines.append(slab.HipSlabEngine(W, H, Dg, z0, d, preset))
+        engines.append(slab.HipSlabEngine(W, H, Dg, z0, d, preset, scheme=scheme))
         z0 += d
     assert z0 == Dg
     cl = slab.LocalSlabCluster(engines, preset)
@@ -36,9 +36,10 @@ def run_slabs(lbm, W, H, Dg, preset, splits, mask, steps, params=None):
     return rho, u, f, cls
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
 @pytest.mark.parametrize("preset", [0, 1])
 @pytest.mark.parametrize("splits", [(32,), (16, 16), (11, 10, 11), (1, 30, 1), (2, 2, 28)])
-def test_slabs_equal_single_domain(oracle, lbm, preset, splits):
+def test_slabs_equal_single_domain(oracle, lbm, preset, splits, scheme):
     W, H, Dg = 72, 24, 32
     o = oracle.Solver(W, H, Dg, preset)
     o.init()
@@ -46,7 +47,7 @@ def test_slabs_equal_single_domain(oracle, lbm, preset, splits):
     o.add_solid(50, 8, 14, 6, 6, 4)
     mask = o.solid_mask()
     o.step(9)
-    rho, u, f, cls = run_slabs(lbm, W, H, Dg, preset, splits, mask, 9)
+    rho, u, f, cls = run_slabs(lbm, W, H, Dg, preset, splits, mask, 9, scheme=scheme)
     np.testing.assert_array_equal(rho, o.density())
     np.testing.assert_array_equal(u, o.velocity())
     fluid = mask == 0
@@ -54,7 +55,8 @@ def test_slabs_equal_single_domain(oracle, lbm, preset, splits):
     np.testing.assert_array_equal(cls, o.classification()[0])
 
 
-def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm):
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm, scheme):
     """No mesh: the outlet quirk rows at y=0 / y=H-1 and the z wrap between the first and the
     last layer cross slab interfaces and the ring link."""
     W, H, Dg = 40, 12, 12
@@ -62,17 +64,18 @@ def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm):
     o.init(); o.step(15)
     mask = np.zeros(W * H * Dg, np.uint8)
     for splits in [(6, 6), (4, 4, 4), (12,)]:
-        rho, u, f, _ = run_slabs(lbm, W, H, Dg, 0, splits, mask, 15)
+        rho, u, f, _ = run_slabs(lbm, W, H, Dg, 0, splits, mask, 15, scheme=scheme)
         np.testing.assert_array_equal(rho, o.density(), err_msg=str(splits))
         np.testing.assert_array_equal(u, o.velocity(), err_msg=str(splits))
         np.testing.assert_array_equal(f, o.populations(), err_msg=str(splits))
 
 
-def test_slabs_cube_64(oracle, lbm):
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_slabs_cube_64(oracle, lbm, scheme):
     o = oracle.Solver(64, 64, 64)
     o.init(); o.load_mesh(CUBE_OBJ)
     mask = o.solid_mask()
     o.step(20)
-    rho, u, _, _ = run_slabs(lbm, 64, 64, 64, 0, (16, 16, 16, 16), mask, 20)
+    rho, u, _, _ = run_slabs(lbm, 64, 64, 64, 0, (16, 16, 16, 16), mask, 20, scheme=scheme)
     np.testing.assert_array_equal(rho, o.density())
     np.testing.assert_array_equal(u, o.velocity())
