@@ -115,11 +115,7 @@ def main():
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
         if obstacle:
-            # the host stage of load_mesh on the GLOBAL domain; each rank installs its own layers
-            gmask, _, rc = lbm.host_voxelize_obj(car, W, H, Dg)
-            assert rc == 0
-            solver.set_solid(gmask.reshape(Dg, H * W)[rank * D:(rank + 1) * D])
-            del gmask
+            solver.load_mesh(car)   # device voxeliser: every slab casts the rays of its own layers
         drv.exchange_mask()
         drv.exchange_populations()
         step = drv.step

@@ -20,6 +20,7 @@
 // HBM-bound integer/float streaming work: no MFMA, no LDS staging.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -679,6 +680,100 @@ __global__ void k_add_rect(unsigned long long* __restrict__ mask, Geo g, int rx,
     const int b0 = (int)(lo - (long long)xw * 64), cnt = (int)(hi - lo);
     const unsigned long long bits = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << b0;
     mask[wi] |= bits;
+}
+
+// ---- device voxeliser (MeshVoxelizer::voxelize, mesh_voxelizer.cpp:146-216, on the GPU) ----------
+// One thread per +X ray (one (y,z) row of the grid), one block per 256 consecutive rows of a z
+// layer.  Triangles stream through LDS in tiles of 256; the z-extent cull is uniform for the
+// block, the y-extent cull and the Moeller-Trumbore test (mesh_voxelizer.cpp:89-121) run per ray
+// in the reference's fp32 operation order (contraction off, IEEE division), so the hit distances
+// -- and with them ceil/floor of the span ends -- equal the host's bit for bit.  Each thread sorts
+// its hits, turns the pairs into bits and writes its row of the packed mask itself (whole words,
+// no atomics); y = 0 becomes the solid floor (lbm_solver.cu:549-553).  A ray with more than
+// VOX_MAX_HITS hits raises `overflow` and the caller falls back to the host voxeliser.
+constexpr int VOX_MAX_HITS = 64;
+constexpr int VOX_TILE = 256;
+struct VoxTri {
+    float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
+    float ymin, ymax, zmin, zmax;
+};
+struct VoxFrame {
+    float gcx, gcy, gcz;  // grid centre (W/2, H/2, D/2)
+    float mcx, mcy, mcz;  // mesh point mapped onto it
+    float scale;
+};
+__device__ __forceinline__ bool vox_hit_plus_x(float ox, float oy, float oz, const VoxTri& t, float& dist) {
+    constexpr float kEps = 0.0000001f;
+    const float e1x = t.v1x - t.v0x, e1y = t.v1y - t.v0y, e1z = t.v1z - t.v0z;
+    const float e2x = t.v2x - t.v0x, e2y = t.v2y - t.v0y, e2z = t.v2z - t.v0z;
+    // h = cross(dir, e2) with dir = (1,0,0), written out as glm::cross evaluates it
+    const float hx = 0.0f * e2z - e2y * 0.0f, hy = 0.0f * e2x - e2z * 1.0f, hz = 1.0f * e2y - e2x * 0.0f;
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    if (a > -kEps && a < kEps) return false;
+    const float f = 1.0f / a;
+    const float sx = ox - t.v0x, sy = oy - t.v0y, sz = oz - t.v0z;
+    const float u = f * (sx * hx + sy * hy + sz * hz);
+    if (u < 0.0f || u > 1.0f) return false;
+    const float qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;
+    const float v = f * (1.0f * qx + 0.0f * qy + 0.0f * qz);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    dist = f * (e2x * qx + e2y * qy + e2z * qz);
+    return dist > kEps;
+}
+__global__ __launch_bounds__(256) void k_voxelize_rows(const VoxTri* __restrict__ tris, int ntris, VoxFrame fr,
+                                                       unsigned long long* __restrict__ mask, Geo g,
+                                                       int* __restrict__ overflow) {
+    __shared__ VoxTri tile[VOX_TILE];
+    const int z = blockIdx.y;
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    const float ox = (0.0f - fr.gcx) / fr.scale + fr.mcx;
+    const float oy = ((float)y - fr.gcy) / fr.scale + fr.mcy;
+    const float oz = ((float)(z + g.z0) - fr.gcz) / fr.scale + fr.mcz;  // z is this context's layer; the grid is the global domain
+    float hits[VOX_MAX_HITS];
+    int nh = 0;
+    bool over = false;
+    for (int base = 0; base < ntris; base += VOX_TILE) {
+        const int cnt = min(VOX_TILE, ntris - base);
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) tile[threadIdx.x] = tris[base + threadIdx.x];
+        __syncthreads();
+        if (y >= g.H) continue;
+        for (int i = 0; i < cnt; i++) {
+            const VoxTri& t = tile[i];
+            if (oz < t.zmin || oz > t.zmax) continue;  // uniform for the block
+            if (oy < t.ymin || oy > t.ymax) continue;
+            float d;
+            if (vox_hit_plus_x(ox, oy, oz, t, d)) {
+                if (nh < VOX_MAX_HITS) hits[nh++] = d; else over = true;
+            }
+        }
+    }
+    if (y >= g.H) return;
+    if (over) { *overflow = 1; return; }
+    for (int i = 1; i < nh; i++) {  // insertion sort (std::sort on the host: same order of values)
+        const float v = hits[i];
+        int j = i - 1;
+        while (j >= 0 && hits[j] > v) { hits[j + 1] = hits[j]; j--; }
+        hits[j + 1] = v;
+    }
+    unsigned long long* row = mask + ((long long)(z + 1) * g.H + y) * g.Wm;
+    for (int w = 0; w < g.Wm; w++) {
+        const int lo = w * 64;
+        const int valid = min(64, g.W - lo);
+        const unsigned long long all = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
+        unsigned long long bits = 0;
+        if (y == 0) {
+            bits = all;  // floor
+        } else {
+            for (int i = 0; i + 1 < nh; i += 2) {
+                const int x0 = max(0, (int)ceilf(hits[i] * fr.scale));
+                const int x1 = min(g.W, (int)floorf(hits[i + 1] * fr.scale));
+                const int a = max(x0, lo) - lo, b = min(x1, lo + 64) - lo;  // [a, b) inside this word
+                if (b > a) bits |= (b - a >= 64 ? ~0ull : ((1ull << (b - a)) - 1ull)) << a;
+            }
+        }
+        row[w] = bits;
+    }
 }
 
 // per-tile path flag: 0 = interior fast path, 1 = full boundary chain, 2 = every cell solid (skipped)
@@ -1344,13 +1439,62 @@ int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
 int lbm_load_mesh(lbm_ctx* c, const char* obj_path) {
     NEED(c);
     if (!obj_path) return fail(c, LBM_ERR_INVALID, "lbm_load_mesh: path is null");
-    if (c->g.Dg != c->g.D)
-        return fail(c, LBM_ERR_STATE, "lbm_load_mesh: voxelise the global domain once and hand each slab its layers with lbm_set_solid_u8");
-    std::vector<uint8_t> host;
-    float scale = 0.0f;
-    const bool loaded = lbmvox::build_wind_tunnel_mask(obj_path, c->g.W, c->g.H, c->g.D, host, &scale);
-    int rc = lbm_set_solid_u8(c, host.data(), host.size());
+    const Geo& g = c->g;
+    // host stage, O(triangles): parse, rotate, bounds, auto-scale (lbm_solver.cu:526-538)
+    lbmvox::Mesh mesh;
+    const bool loaded = mesh.load_obj(obj_path);
+    if (!loaded) mesh.set_triangles(nullptr, 0);
+    mesh.rotate_y(-90.0f);
+    const lbmvox::Vec3 lo = mesh.min_bound(), hi = mesh.max_bound();
+    const float sx = ((float)g.W * 0.8f) / (hi.x - lo.x);
+    const float sy = ((float)g.H * 0.8f) / (hi.y - lo.y);
+    const float sz = ((float)g.Dg * 0.8f) / (hi.z - lo.z);
+    const float scale = std::min({sx, sy, sz});
+    int rc = before_mask_change(c);
     if (rc) return rc;
+    bool on_device = true;
+    if (const char* t = getenv("LBM_VOXELIZE")) on_device = strcmp(t, "host") != 0;
+    if (on_device) {
+        // device stage, O(D*H*triangles): the ray casting (mesh_voxelizer.cpp:146-216), straight into the packed mask
+        const std::vector<lbmvox::Triangle>& tr = mesh.triangles();
+        std::vector<VoxTri> vt(tr.size());
+        for (size_t i = 0; i < tr.size(); i++) {
+            const lbmvox::Triangle& t = tr[i];
+            vt[i] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x, t.v1.y, t.v1.z, t.v2.x, t.v2.y, t.v2.z,
+                     std::min({t.v0.y, t.v1.y, t.v2.y}), std::max({t.v0.y, t.v1.y, t.v2.y}),
+                     std::min({t.v0.z, t.v1.z, t.v2.z}), std::max({t.v0.z, t.v1.z, t.v2.z})};
+        }
+        VoxFrame fr;
+        fr.gcx = g.W / 2.0f; fr.gcy = g.H / 2.0f; fr.gcz = g.Dg / 2.0f;   // mesh_voxelizer.cpp:148-153
+        fr.mcx = (lo.x + hi.x) / 2;
+        fr.mcy = lo.y + fr.gcy / scale;
+        fr.mcz = (lo.z + hi.z) / 2;
+        fr.scale = scale;
+        VoxTri* d_tris = nullptr;
+        int* d_over = nullptr;
+        HIPCHK(c, hipMalloc(&d_tris, std::max<size_t>(1, vt.size()) * sizeof(VoxTri)));
+        hipError_t e = hipMalloc(&d_over, sizeof(int));
+        int over = 0;
+        if (e == hipSuccess) e = hipMemsetAsync(d_over, 0, sizeof(int), c->stream);
+        if (e == hipSuccess && !vt.empty()) e = hipMemcpyAsync(d_tris, vt.data(), vt.size() * sizeof(VoxTri), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_voxelize_rows, dim3((g.H + 255) / 256, g.D), dim3(256), 0, c->stream, d_tris, (int)vt.size(), fr, c->mask, g, d_over);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_tris); (void)hipFree(d_over);
+        if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_load_mesh: %s", hipGetErrorString(e));
+        c->mask_dirty = true;
+        on_device = over == 0;  // a ray with more hits than the kernel keeps: redo on the host
+    }
+    if (!on_device) {
+        std::vector<uint8_t> host((size_t)g.W * g.H * g.Dg, 0);
+        mesh.voxelize(host.data(), g.W, g.H, g.Dg, scale);
+        for (int z = 0; z < g.Dg; z++) memset(host.data() + (size_t)z * g.W * g.H, 255, (size_t)g.W);
+        rc = lbm_set_solid_u8(c, host.data() + (size_t)g.z0 * g.W * g.H, (size_t)cells(c));
+        if (rc) return rc;
+    }
     if (!loaded) return fail(c, LBM_ERR_IO, "lbm_load_mesh: cannot read '%s' (floor-only mask installed, as the reference leaves it)", obj_path);
     return LBM_OK;
 }
