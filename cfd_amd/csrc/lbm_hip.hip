@@ -1013,6 +1013,23 @@ __global__ void k_curl(const float4* __restrict__ u, float* __restrict__ curl, i
     curl[((long long)z * H + y) * W + x] = sqrtf(cxv * cxv + cyv * cyv + czv * czv);
 }
 
+// Derived fields for the visualisation consumers either side of the path (the reference's renderer
+// samples u as an RGBA32F volume: renderer.cpp:1382-1389, raymarch.frag / streamline.comp).
+// strided sample of u: out[(k*ny + j)*nx + i] = u(i*sx, j*sy, k*sz); speed = |u.xyz|
+__global__ void k_sample_velocity(const float4* __restrict__ u, float4* __restrict__ out, int W, int H,
+                                  int nx, int ny, int nz, int sx, int sy, int sz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * ny * nz) return;
+    const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((long long)nx * ny));
+    out[i] = u[((long long)iz * sz * H + (long long)iy * sy) * W + (long long)ix * sx];
+}
+__global__ void k_speed(const float4* __restrict__ u, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = u[i];
+    out[i] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);  // cuda_math::length, cuda_math.cuh:142-145
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1598,6 +1615,43 @@ int lbm_read_curl(lbm_ctx* c, float* curl, size_t n) {
     int rc = lbm_compute_curl(c);
     if (rc) return rc;
     return read_back(c, curl, c->curl, n * sizeof(float));
+}
+
+int lbm_read_velocity_strided(lbm_ctx* c, int sx, int sy, int sz, float* u, size_t n) {
+    NEED(c);
+    if (sx < 1 || sy < 1 || sz < 1) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided: strides must be positive");
+    const int nx = (c->g.W + sx - 1) / sx, ny = (c->g.H + sy - 1) / sy, nz = (c->g.fnz + sz - 1) / sz;
+    const size_t need = (size_t)nx * ny * nz;
+    if (!u || n != need) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided: need %zu x 4 floats (%d x %d x %d samples)", need, nx, ny, nz);
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = materialise_fields(c);
+    if (rc) return rc;
+    float4* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, need * sizeof(float4)));
+    hipLaunchKernelGGL(k_sample_velocity, dim3(blocks_for((long long)need, 256)), dim3(256), 0, c->stream, c->u, d, c->g.W, c->g.H, nx, ny, nz, sx, sy, sz);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(u, d, need * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_read_velocity_strided: %s", hipGetErrorString(e));
+    return LBM_OK;
+}
+
+int lbm_read_speed(lbm_ctx* c, float* speed, size_t n) {
+    NEED(c);
+    if (!speed || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_speed: need %lld floats", field_cells(c));
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = materialise_fields(c);
+    if (rc) return rc;
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
+    hipLaunchKernelGGL(k_speed, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->u, d, (long long)n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(speed, d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_read_speed: %s", hipGetErrorString(e));
+    return LBM_OK;
 }
 
 int lbm_read_solid_u8(lbm_ctx* c, uint8_t* mask, size_t n) {

@@ -135,6 +135,15 @@ int lbm_read_density(lbm_ctx* ctx, float* rho, size_t n);
 int lbm_read_velocity(lbm_ctx* ctx, float* u_xyzw, size_t n);
 int lbm_read_solid_u8(lbm_ctx* ctx, uint8_t* mask, size_t n);
 int lbm_read_curl(lbm_ctx* ctx, float* curl, size_t n);
+/* Derived fields for the consumers downstream of the path (the reference's renderer samples u as an
+ * RGBA32F volume and colours by |u|: renderer.cpp:1382-1389, Shaders/raymarch.frag:93-128,
+ * Shaders/streamline.comp:36-62).  Both are computed on the device from the fields of the current
+ * field window (nz layers):
+ *   lbm_read_velocity_strided: u at every (i*sx, j*sy, k*sz), n = ceil(W/sx)*ceil(H/sy)*ceil(nz/sz)
+ *   samples of 4 floats, x fastest -- a down-sampled volume without moving the full field to the host;
+ *   lbm_read_speed: |u.xyz| per cell (cuda_math::length, cuda_math.cuh:142-145), n = W*H*nz. */
+int lbm_read_velocity_strided(lbm_ctx* ctx, int sx, int sy, int sz, float* u_xyzw, size_t n);
+int lbm_read_speed(lbm_ctx* ctx, float* speed, size_t n);
 /* Current populations in the reference layout f[k*n + idx] (d_f, lbm_solver.cuh:62). */
 int lbm_read_populations(lbm_ctx* ctx, float* f, size_t n_times_19);
 int lbm_write_populations(lbm_ctx* ctx, const float* f, size_t n_times_19);

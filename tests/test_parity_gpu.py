@@ -209,3 +209,20 @@ def test_field_window(oracle, lbm, scheme):
     o.step(1); g.step(1)
     np.testing.assert_array_equal(g.density(), o.density())
     np.testing.assert_array_equal(g.curl_field(), (o.compute_curl(), o.curl_field())[1])
+
+
+def test_derived_fields(oracle, lbm):
+    """lbm_read_velocity_strided / lbm_read_speed against the oracle's u."""
+    W, H, D = 70, 33, 17
+    o, g = both(oracle, lbm, W, H, D)
+    for s in (o, g):
+        s.init(); s.add_solid(20, 0, 4, 9, 11, 9); s.step(12)
+    u = o.velocity().reshape(D, H, W, 4)
+    for st in [(1, 1, 1), (4, 2, 3), (7, 5, 6), (100, 100, 100)]:
+        np.testing.assert_array_equal(g.velocity_strided(*st), u[::st[2], ::st[1], ::st[0]])
+    x, y, z = u[..., 0].ravel(), u[..., 1].ravel(), u[..., 2].ravel()
+    np.testing.assert_array_equal(g.speed(), np.sqrt((x * x + y * y) + z * z))
+    g.set_field_window(5, 6)
+    np.testing.assert_array_equal(g.velocity_strided(3, 3, 2), u[5:11][::2, ::3, ::3])
+    with pytest.raises(lbm.LbmError):
+        g.velocity_strided(0, 1, 1)
