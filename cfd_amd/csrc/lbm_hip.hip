@@ -1172,13 +1172,14 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
 
 // one AA launch over layers [zl_begin, zl_begin + nlayers), or over the two layers zl_begin and
 // zl_second when zl_second > 0; the caller flips the phase with aa_flip() once the step is complete
-static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, int zl_second) {
+static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, int zl_second, hipStream_t stream = nullptr) {
     if (nlayers <= 0) return LBM_OK;
+    if (!stream) stream = c->stream;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
     const int zrev = ((c->tune & 4) && nlayers == c->g.D) ? c->zrev : 0;
 #define LBM_AA(PRESET, PHASE, TUNE)                                                                               \
-    hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, c->stream, c->f[0], c->ob[c->ob_cur],  \
+    hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, stream, c->f[0], c->ob[c->ob_cur],     \
                        c->ob[1 - c->ob_cur], c->mask, c->flags, c->rho, c->u, c->g, c->p, c->segsx_log2, zrev,     \
                        want_moments, zl_begin, zl_second)
 #define LBM_AA_T(PRESET, PHASE)                       \
@@ -1840,12 +1841,13 @@ static inline size_t halo_tail_floats(const lbm_ctx* c) {
 // AA: is the buffer in the streamed layout once the step in flight (if any) is complete?
 static inline int aa_streamed_now(const lbm_ctx* c) { return (c->split_phase ? c->aa_phase ^ 1 : c->aa_phase) == 0; }
 static inline float* aa_newest_ob(lbm_ctx* c) { return c->split_phase ? c->ob[1 - c->ob_cur] : c->ob[c->ob_cur]; }
-static int aa_halo(lbm_ctx* c, int side, float* msg, bool pack) {
+static int aa_halo(lbm_ctx* c, int side, float* msg, bool pack, hipStream_t stream = nullptr) {
     const long long per = c->g.mlayer > (long long)OB_N * c->g.H ? c->g.mlayer : (long long)OB_N * c->g.H;
+    if (!stream) stream = c->stream;
     if (pack)
-        hipLaunchKernelGGL(k_aa_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
+        hipLaunchKernelGGL(k_aa_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
     else
-        hipLaunchKernelGGL(k_aa_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
+        hipLaunchKernelGGL(k_aa_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, stream, c->f[0], aa_newest_ob(c), msg, c->g, side, aa_streamed_now(c));
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
 }
@@ -1942,12 +1944,13 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
     if (c->scheme == LBM_SCHEME_AA) {
         // in place: the boundary layers, then two small pack launches (the layout of the moment decides
         // which slots travel, see k_aa_halo_pack); rho/u are written when the field window is not empty
+        hipStream_t bs = c->stream_b ? c->stream_b : c->stream;  // boundary layers + packs feed the exchange
         rc = ensure_field_buffers(c);
-        if (!rc) rc = launch_aa(c, c->g.fnz > 0, 1, c->g.D > 1 ? 2 : 1, c->g.D);
+        if (!rc) rc = launch_aa(c, c->g.fnz > 0, 1, c->g.D > 1 ? 2 : 1, c->g.D, bs);
         if (rc) return rc;
         c->split_phase = 1;
-        if (d_msg_bottom) rc = aa_halo(c, 0, d_msg_bottom, true);
-        if (!rc && d_msg_top) rc = aa_halo(c, 1, d_msg_top, true);
+        if (d_msg_bottom) rc = aa_halo(c, 0, d_msg_bottom, true, bs);
+        if (!rc && d_msg_top) rc = aa_halo(c, 1, d_msg_top, true, bs);
         return rc;
     }
     // one launch for both boundary layers; it writes the outgoing messages as it goes

@@ -227,13 +227,15 @@ class SlabSolver:
                 self.t.wait(h)
             else:
                 # two streams: boundary layers + exchange on the side stream, interior on the main
-                # stream at the same time
+                # stream at the same time.  The interior launch is issued BEFORE the RCCL calls:
+                # enqueueing a send/recv group costs the host ~100 us, and the GPU would sit idle
+                # behind the short boundary kernel for that long if the interior came after it.
                 side.wait_stream(main)                 # previous step's unpack / swap is done
                 with torch.cuda.stream(side):
                     e.step_boundary(msg_b, msg_t)      # library launches on the side stream
-                    h = self.t.exchange(self._items(self.send, self.recv))
                 e.step_phase_interior()
                 with torch.cuda.stream(side):
+                    h = self.t.exchange(self._items(self.send, self.recv))   # ordered behind the boundary layers only
                     self.t.wait(h)
                 main.wait_stream(side)
             e.halo_unpack_both(rcv_b, rcv_t)

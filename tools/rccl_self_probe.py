@@ -20,7 +20,13 @@ eng.solver.init(); eng.solver.add_solid(20, 0, 10, 8, 20, 20)
 drv.exchange_mask(); drv.exchange_populations(); drv.step(12)
 torch.cuda.synchronize()
 print("self-ring bit-identical:", np.array_equal(ref.density(), eng.solver.density()) and np.array_equal(ref.velocity(), eng.solver.velocity()), flush=True)
-for dims in [(256, 256, 256), (256, 256, 64)]:
+eng = slab.HipSlabEngine(W, H, D, 0, D, lbm.PRESET_WIND_TUNNEL, device=0, scheme=lbm.SCHEME_AA)
+drv = slab.SlabSolver(eng, lbm.PRESET_WIND_TUNNEL, 1, 0, slab.TorchP2P())
+eng.solver.init(); eng.solver.add_solid(20, 0, 10, 8, 20, 20)
+drv.exchange_mask(); drv.exchange_populations(); drv.step(12)
+torch.cuda.synchronize()
+print("AA self-ring bit-identical:", np.array_equal(ref.density(), eng.solver.density()) and np.array_equal(ref.velocity(), eng.solver.velocity()), flush=True)
+for dims in [(256, 256, 256), (256, 256, 64), (1024, 512, 64)]:
     W, H, D = dims
     for preset in (lbm.PRESET_WIND_TUNNEL, lbm.PRESET_CAVITY):
         eng = slab.HipSlabEngine(W, H, D, 0, D, preset, device=0)
