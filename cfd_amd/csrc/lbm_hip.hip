@@ -1076,6 +1076,7 @@ struct lbm_ctx {
     long long pop_floats = 0;  // floats of one population buffer behind f[i]
     long long guard_floats = 0;  // AA: floats allocated in front of f[0]
     int layout = LBM_LAYOUT_ROWS;
+    unsigned lds_pad = 0;      // dynamic LDS bytes per block of the step kernel: caps the blocks per CU (occupancy throttle)
     std::string err;
 };
 
@@ -1153,7 +1154,7 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
     const int zrev = (MODE == 0 && (c->tune & 4)) ? c->zrev : 0;
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
-    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), 0, stream, fin, fout, c->mask, \
+    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
                        c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top)
 #define LBM_LAUNCH_T(PRESET)                          \
     switch (c->tune & 3) {                            \
@@ -1278,7 +1279,9 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     g.fz0 = 0; g.fnz = depth;
     c->scheme = o.scheme;
     const bool aa = o.scheme == LBM_SCHEME_AA;
-    g.Wp = ((aa ? width + 2 : width) + 31) / 32 * 32;  // AA: ghost slots x = -1 and x = W in the row padding
+    int wp_align = 32;
+    if (const char* t = getenv("LBM_WP_ALIGN")) wp_align = std::max(32, atoi(t) / 32 * 32);
+    g.Wp = ((aa ? width + 2 : width) + wp_align - 1) / wp_align * wp_align;  // AA: ghost slots x = -1 and x = W in the row padding
     g.Wm = (width + 63) / 64;
     g.Wt = g.Wm;
     g.mlayer = (long long)height * g.Wp;
@@ -1319,6 +1322,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     // 5.5, with alternating z 6.03 -> plain nt/nt is the default there.
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
+    if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
     c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
     auto cleanup = [&](int code) {

@@ -69,6 +69,27 @@ class hip_buffer {
             std::memcpy(host_data, tmp.data(), size * sizeof(T));
         }
     }
+    // cuda_buffer.cuh:72-77 as the solver uses it (lbm_solver.cu:555: the whole solid mask from the
+    // host).  Density / velocity / curl are results of step() here, not inputs: writes to them are
+    // rejected with a log line, where the reference would overwrite values its next step recomputes.
+    void copy_from_host(const T* host_data, size_t size) {
+        if (!m_ctx || size > m_size) return;
+        if (m_field != field::solid || size != m_size) {
+            std::fprintf(stderr, "[error] copy_from_host: only the whole solid mask can be written\n");
+            return;
+        }
+        LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, reinterpret_cast<const uint8_t*>(host_data), size));
+    }
+    // cuda_buffer.cuh:86-91 as the solver uses it (lbm_solver.cu:415: d_solid.memset(0))
+    void memset(int value) {
+        if (!m_ctx) return;
+        if (m_field != field::solid) {
+            std::fprintf(stderr, "[error] memset: only the solid mask can be written\n");
+            return;
+        }
+        std::vector<uint8_t> v(m_size, static_cast<uint8_t>(value));
+        LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, v.data(), v.size()));
+    }
     // device pointer in the reference wire format, up to date and synchronised
     T* get_data() {
         if (!m_ctx) {
@@ -103,12 +124,14 @@ class hip_buffer {
 
 class lbm_solver {
    public:
-    lbm_solver(int width, int height, int depth, int preset = LBM_PRESET_WIND_TUNNEL_REF)
+    lbm_solver(int width, int height, int depth, int preset = LBM_PRESET_WIND_TUNNEL_REF,
+               int scheme = LBM_SCHEME_AB)
         : m_width(width), m_height(height), m_depth(depth) {
         lbm_opts o{};
         o.struct_size = sizeof(lbm_opts);
         o.device = -1;
         o.preset = preset;
+        o.scheme = scheme;
         o.plane_skew_bytes = -1;
         LBM_CHECK(nullptr, lbm_create(&m_ctx, width, height, depth, &o));
         const size_t n = static_cast<size_t>(width) * height * depth;
