@@ -67,6 +67,13 @@ __device__ __forceinline__ long long cell_off(const Geo& g, int x, int y, int zl
     return (long long)zl * g.layer + (long long)y * g.row + x;
 }
 
+// flat thread index of the 1-D kernels.  A dispatch holds at most 2^32 - 1 work-items per grid
+// dimension, and a buffer sized to HBM has more floats than that, so those kernels are launched on
+// the 2-D grid of grid1() and flatten it here.
+__device__ __forceinline__ long long gidx() {
+    return ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+}
+
 __device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long* __restrict__ mask,
                                          int x, int y, int zl) {
     const unsigned long long w = mask[((long long)zl * g.H + y) * g.Wm + (x >> 6)];
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(256) void k_aa_step(
 }
 
 __global__ void k_ob_fill(float* __restrict__ a, float* __restrict__ b, long long per_plane) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     if (i >= per_plane * OB_N) return;
     const float w = weight(OB_PLANE[i / per_plane]);
     a[i] = w;
@@ -537,7 +544,7 @@ __global__ void k_ob_fill(float* __restrict__ a, float* __restrict__ b, long lon
 // solid cells of the outlet column keep their frozen value in both side buffers
 __global__ void k_ob_sync(const float* __restrict__ cur, float* __restrict__ other,
                           const unsigned long long* __restrict__ mask, Geo g) {
-    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long col = gidx();
     if (col >= (long long)g.D * g.H) return;
     const int z = (int)(col / g.H), y = (int)(col - (long long)z * g.H);
     if (!solid_at(g, mask, g.W - 1, y, z + 1)) return;
@@ -549,7 +556,7 @@ __global__ void k_ob_sync(const float* __restrict__ cur, float* __restrict__ oth
 // the A/B scheme; identical to the reference whenever the cell was solid since init()).
 __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsigned long long* __restrict__ prev,
                                 const unsigned long long* __restrict__ mask, Geo g, int phase) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -569,7 +576,7 @@ __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsi
 
 // canonical f[k*n + idx] <-> the in-place layout of the moment
 __global__ void k_aa_export(const float* __restrict__ M, float* __restrict__ dense, Geo g, int phase) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -584,7 +591,7 @@ __global__ void k_aa_export(const float* __restrict__ M, float* __restrict__ den
 }
 __global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, float* __restrict__ ob_b,
                             const float* __restrict__ dense, Geo g) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -614,7 +621,7 @@ __global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, flo
 // belongs to.
 __global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, Geo g, int rows_layout,
                               long long first, long long last) {
-    const long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = first + gidx();
     if (i >= last) return;
     long long k;
     if (rows_layout) {
@@ -630,7 +637,7 @@ __global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, Ge
 }
 
 __global__ void k_fill_fields(float* __restrict__ rho, float4* __restrict__ u, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     if (i >= n) return;
     rho[i] = 1.0f;
     u[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -638,7 +645,7 @@ __global__ void k_fill_fields(float* __restrict__ rho, float4* __restrict__ u, l
 
 // dense u8 mask (reference wire format) -> bit-packed words of the owned layers
 __global__ void k_pack_mask(const unsigned char* __restrict__ dense, unsigned long long* __restrict__ mask, Geo g) {
-    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // word index over owned rows
+    const long long wi = gidx();  // word index over owned rows
     const long long nwords = (long long)g.D * g.H * g.Wm;
     if (wi >= nwords) return;
     const long long row = wi / g.Wm;
@@ -651,7 +658,7 @@ __global__ void k_pack_mask(const unsigned char* __restrict__ dense, unsigned lo
 }
 
 __global__ void k_unpack_mask(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -663,7 +670,7 @@ __global__ void k_unpack_mask(const unsigned long long* __restrict__ mask, unsig
 // k_add_solid_rect (lbm_solver.cu:498-513) on the packed mask: one thread per word, no atomics.
 // Coordinates are global; this context owns global layers [z0, z0+D).
 __global__ void k_add_rect(unsigned long long* __restrict__ mask, Geo g, int rx, int ry, int rz, int rw, int rh, int rd) {
-    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long wi = gidx();
     const long long nwords = (long long)(g.D + 2) * g.H * g.Wm;  // ghost layers included
     if (wi >= nwords) return;
     const long long row = wi / g.Wm;
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(256) void k_voxelize_rows(const VoxTri* __restrict_
 // per-tile path flag: 0 = interior fast path, 1 = full boundary chain, 2 = every cell solid (skipped)
 template <int PRESET>
 __global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ flags, Geo g) {
-    const long long ti = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ti = gidx();
     const long long ntiles = (long long)g.D * g.H * g.Wt;
     if (ti >= ntiles) return;
     const long long row = ti / g.Wt;
@@ -813,7 +820,7 @@ __global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsign
 // One copy cur -> other after the mask (or the populations) changed gives the same state.
 __global__ void k_sync_solid(const float* __restrict__ cur, float* __restrict__ other,
                              const unsigned long long* __restrict__ mask, Geo g) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -827,7 +834,7 @@ __global__ void k_sync_solid(const float* __restrict__ cur, float* __restrict__ 
 
 template <int PRESET>
 __global__ void k_classify(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ cls, Geo g) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     const long long n = (long long)g.W * g.H * g.D;
     if (i >= n) return;
     const long long row = i / g.W;
@@ -1018,13 +1025,13 @@ __global__ void k_curl(const float4* __restrict__ u, float* __restrict__ curl, i
 // strided sample of u: out[(k*ny + j)*nx + i] = u(i*sx, j*sy, k*sz); speed = |u.xyz|
 __global__ void k_sample_velocity(const float4* __restrict__ u, float4* __restrict__ out, int W, int H,
                                   int nx, int ny, int nz, int sx, int sy, int sz) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     if (i >= (long long)nx * ny * nz) return;
     const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((long long)nx * ny));
     out[i] = u[((long long)iz * sz * H + (long long)iy * sy) * W + (long long)ix * sx];
 }
 __global__ void k_speed(const float4* __restrict__ u, float* __restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = gidx();
     if (i >= n) return;
     const float4 v = u[i];
     out[i] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);  // cuda_math::length, cuda_math.cuh:142-145
@@ -1110,6 +1117,12 @@ static int fail(lbm_ctx* c, int code, const char* fmt, ...) {
 static inline long long cells(const lbm_ctx* c) { return (long long)c->g.W * c->g.H * c->g.D; }
 static inline long long field_cells(const lbm_ctx* c) { return (long long)c->g.W * c->g.H * c->g.fnz; }
 static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+// grid of the 1-D kernels that index with gidx(): at most 2^20 blocks in x, the rest in y
+static inline dim3 grid1(long long n, int bs = 256) {
+    const long long blocks = (n + bs - 1) / bs;
+    const long long gx = blocks < (1ll << 20) ? (blocks > 0 ? blocks : 1) : (1ll << 20);
+    return dim3((unsigned)gx, (unsigned)((blocks + gx - 1) / gx));
+}
 
 static int ensure_field_buffers(lbm_ctx* c) {
     const long long n = field_cells(c);
@@ -1124,20 +1137,20 @@ static int refresh_mask_state(lbm_ctx* c) {
     if (!c->mask_dirty) return LBM_OK;
     const long long ntiles = (long long)c->g.D * c->g.H * c->g.Wt;
     if (c->preset == LBM_PRESET_CAVITY)
-        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_CAVITY>, dim3(blocks_for(ntiles, 256)), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
+        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_CAVITY>, grid1(ntiles), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
     else
-        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_WIND_TUNNEL_REF>, dim3(blocks_for(ntiles, 256)), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
+        hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_WIND_TUNNEL_REF>, grid1(ntiles), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
     HIPCHK(c, hipGetLastError());
     if (c->scheme == LBM_SCHEME_AA) {
-        hipLaunchKernelGGL(k_aa_refluidize, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0],
+        hipLaunchKernelGGL(k_aa_refluidize, grid1(cells(c)), dim3(256), 0, c->stream, c->f[0],
                            c->ob[c->ob_cur], c->prev_mask, c->mask, c->g, c->aa_phase);
         HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(k_ob_sync, dim3(blocks_for((long long)c->g.D * c->g.H, 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_ob_sync, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
                            c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->prev_mask, c->mask, c->mask_bytes, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        hipLaunchKernelGGL(k_sync_solid, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream,
                            c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
         HIPCHK(c, hipGetLastError());
     }
@@ -1218,7 +1231,7 @@ static int materialise_fields(lbm_ctx* c) {
     int rc = ensure_field_buffers(c);
     if (rc) return rc;
     if (c->fields == FIELDS_INIT) {
-        hipLaunchKernelGGL(k_fill_fields, dim3(blocks_for(field_cells(c), 256)), dim3(256), 0, c->stream, c->rho, c->u, field_cells(c));
+        hipLaunchKernelGGL(k_fill_fields, grid1(field_cells(c)), dim3(256), 0, c->stream, c->rho, c->u, field_cells(c));
         HIPCHK(c, hipGetLastError());
     } else if (c->scheme == LBM_SCHEME_AA) {
         return fail(c, LBM_ERR_STATE, "AA scheme: rho/u of a new field window exist after the next lbm_step()");
@@ -1388,12 +1401,12 @@ int lbm_init(lbm_ctx* c) {
     // the whole allocation: the AA scheme's ghost slots (y = -1, z = -1) lie in the skew region behind
     // the previous plane / in the front guard
     const long long first = -c->guard_floats, last = c->pop_floats;
-    hipLaunchKernelGGL(k_fill_planes, dim3(blocks_for(last - first, 256)), dim3(256), 0, c->stream, c->f[0],
+    hipLaunchKernelGGL(k_fill_planes, grid1(last - first), dim3(256), 0, c->stream, c->f[0],
                        c->f[1] ? c->f[1] : c->f[0], c->g, c->layout == LBM_LAYOUT_ROWS ? 1 : 0, first, last);
     HIPCHK(c, hipGetLastError());
     if (c->scheme == LBM_SCHEME_AA) {
         const long long per = (long long)(c->g.D + 2) * c->g.H;
-        hipLaunchKernelGGL(k_ob_fill, dim3(blocks_for(per * OB_N, 256)), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
+        hipLaunchKernelGGL(k_ob_fill, grid1(per * OB_N), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
         HIPCHK(c, hipGetLastError());
         c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
     }
@@ -1431,7 +1444,7 @@ int lbm_add_solid_rect(lbm_ctx* c, int x, int y, int z, int w, int h, int d) {
     int rc = before_mask_change(c);
     if (rc) return rc;
     const long long nwords = (long long)(c->g.D + 2) * c->g.H * c->g.Wm;
-    hipLaunchKernelGGL(k_add_rect, dim3(blocks_for(nwords, 256)), dim3(256), 0, c->stream, c->mask, c->g, x, y, z, w, h, d);
+    hipLaunchKernelGGL(k_add_rect, grid1(nwords), dim3(256), 0, c->stream, c->mask, c->g, x, y, z, w, h, d);
     HIPCHK(c, hipGetLastError());
     c->mask_dirty = true;
     return LBM_OK;
@@ -1448,7 +1461,7 @@ int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
     hipError_t e = hipMemcpyAsync(dense, mask, n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const long long nwords = (long long)c->g.D * c->g.H * c->g.Wm;
-        hipLaunchKernelGGL(k_pack_mask, dim3(blocks_for(nwords, 256)), dim3(256), 0, c->stream, dense, c->mask, c->g);
+        hipLaunchKernelGGL(k_pack_mask, grid1(nwords), dim3(256), 0, c->stream, dense, c->mask, c->g);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1633,7 +1646,7 @@ int lbm_read_velocity_strided(lbm_ctx* c, int sx, int sy, int sz, float* u, size
     if (rc) return rc;
     float4* d = nullptr;
     HIPCHK(c, hipMalloc(&d, need * sizeof(float4)));
-    hipLaunchKernelGGL(k_sample_velocity, dim3(blocks_for((long long)need, 256)), dim3(256), 0, c->stream, c->u, d, c->g.W, c->g.H, nx, ny, nz, sx, sy, sz);
+    hipLaunchKernelGGL(k_sample_velocity, grid1((long long)need), dim3(256), 0, c->stream, c->u, d, c->g.W, c->g.H, nx, ny, nz, sx, sy, sz);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(u, d, need * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1650,7 +1663,7 @@ int lbm_read_speed(lbm_ctx* c, float* speed, size_t n) {
     if (rc) return rc;
     float* d = nullptr;
     HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
-    hipLaunchKernelGGL(k_speed, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->u, d, (long long)n);
+    hipLaunchKernelGGL(k_speed, grid1((long long)n), dim3(256), 0, c->stream, c->u, d, (long long)n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(speed, d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1664,7 +1677,7 @@ int lbm_read_solid_u8(lbm_ctx* c, uint8_t* mask, size_t n) {
     if (!mask || n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_solid_u8: need %lld bytes", cells(c));
     unsigned char* dense = nullptr;
     HIPCHK(c, hipMalloc(&dense, n));
-    hipLaunchKernelGGL(k_unpack_mask, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, dense, c->g);
+    hipLaunchKernelGGL(k_unpack_mask, grid1((long long)n), dim3(256), 0, c->stream, c->mask, dense, c->g);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(mask, dense, n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1680,9 +1693,9 @@ int lbm_read_classification(lbm_ctx* c, uint8_t* cls, size_t n19) {
     unsigned char* d = nullptr;
     HIPCHK(c, hipMalloc(&d, n19));
     if (c->preset == LBM_PRESET_CAVITY)
-        hipLaunchKernelGGL(k_classify<LBM_PRESET_CAVITY>, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, d, c->g);
+        hipLaunchKernelGGL(k_classify<LBM_PRESET_CAVITY>, grid1((long long)n), dim3(256), 0, c->stream, c->mask, d, c->g);
     else
-        hipLaunchKernelGGL(k_classify<LBM_PRESET_WIND_TUNNEL_REF>, dim3(blocks_for((long long)n, 256)), dim3(256), 0, c->stream, c->mask, d, c->g);
+        hipLaunchKernelGGL(k_classify<LBM_PRESET_WIND_TUNNEL_REF>, grid1((long long)n), dim3(256), 0, c->stream, c->mask, d, c->g);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(cls, d, n19, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1713,13 +1726,13 @@ static int aa_copy_populations(lbm_ctx* c, float* host, bool to_host) {
     HIPCHK(c, hipMalloc(&dense, bytes));
     hipError_t e = hipSuccess;
     if (to_host) {
-        hipLaunchKernelGGL(k_aa_export, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0], dense, c->g, c->aa_phase);
+        hipLaunchKernelGGL(k_aa_export, grid1(cells(c)), dim3(256), 0, c->stream, c->f[0], dense, c->g, c->aa_phase);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(host, dense, bytes, hipMemcpyDeviceToHost, c->stream);
     } else {
         e = hipMemcpyAsync(dense, host, bytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_aa_import, dim3(blocks_for(cells(c), 256)), dim3(256), 0, c->stream, c->f[0], c->ob[0], c->ob[1], dense, c->g);
+            hipLaunchKernelGGL(k_aa_import, grid1(cells(c)), dim3(256), 0, c->stream, c->f[0], c->ob[0], c->ob[1], dense, c->g);
             e = hipGetLastError();
         }
     }
@@ -1769,7 +1782,7 @@ int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, ui
     if (d_solid) {  // dense copy of the bit-packed mask in the reference's wire format
         const long long n = cells(c);
         if (!c->solid_dense) HIPCHK(c, hipMalloc(&c->solid_dense, (size_t)n));
-        hipLaunchKernelGGL(k_unpack_mask, dim3(blocks_for(n, 256)), dim3(256), 0, c->stream, c->mask, c->solid_dense, c->g);
+        hipLaunchKernelGGL(k_unpack_mask, grid1(n), dim3(256), 0, c->stream, c->mask, c->solid_dense, c->g);
         HIPCHK(c, hipGetLastError());
         *d_solid = c->solid_dense;
     }
