@@ -80,10 +80,21 @@ __device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long*
     return (w >> (x & 63)) & 1ull;
 }
 
+// Populations whose A/B fast-path load is non-temporal when TUNE bit 0 is set (bit k = population k).
+// Default: the ten x-shifted populations keep the default policy -- their misaligned loads touch a
+// second 128-byte line that the neighbouring wave needs too; nt would drop it after one use
+// (+2 % at 256^3, tools/tune_bench.py).
+#ifndef LBM_NT_SET
+#define LBM_NT_SET 0x78079u   // cx == 0: k = 0, 3, 4, 5, 6, 15, 16, 17, 18
+#endif
 // population load / store with an explicit cache policy (TUNE bit 0: nt loads, bit 1: sc1 stores)
 template <int TUNE>
 __device__ __forceinline__ float ldf(const float* p) {
     return (TUNE & 1) ? __builtin_nontemporal_load(p) : *p;
+}
+template <int TUNE, int K>
+__device__ __forceinline__ float ldk(const float* p) {
+    return ((TUNE & 1) && ((LBM_NT_SET >> K) & 1u)) ? __builtin_nontemporal_load(p) : *p;
 }
 template <int TUNE>
 __device__ __forceinline__ void stf(float* p, float v) {
@@ -213,18 +224,18 @@ __device__ __forceinline__ float gather_fast(const Geo& g, const float* __restri
     constexpr int cx = CX[K];
     const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
                        (long long)(y - CY[K]) * g.row;
-    if (cx == 0) return ldf<TUNE>(row + x);
+    if (cx == 0) return ldk<TUNE, K>(row + x);
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
         if (cx == 1) {
-            const float v = ldf<TUNE>(row + x - 1);  // x = 0 reads the pad/previous row: in bounds, discarded
+            const float v = ldk<TUNE, K>(row + x - 1);  // x = 0 reads the pad/previous row: in bounds, discarded
             return x == 0 ? weight(K) * inlet_e : v;
         }
         const int xs = x + 1 < g.W ? x + 1 : g.W - 1;  // outlet: copy from x = W-1 (ny, nz in range here)
-        return ldf<TUNE>(row + xs);
+        return ldk<TUNE, K>(row + xs);
     } else {
         const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
         const float* p = wall ? fin + (long long)INV[K] * g.plane + own : row + x - cx;  // one load either way
-        return ldf<TUNE>(p);
+        return ldk<TUNE, K>(p);
     }
 }
 

@@ -96,7 +96,7 @@ def load_library(path=None):
     """dlopen the HIP library; raises if it is missing (no fallback)."""
     global _lib
     if _lib is None or path is not None:
-        p = path or LIB_PATH
+        p = path or os.environ.get("LBM_LIB") or LIB_PATH   # LBM_LIB: an experimental build (tuning probes)
         if not os.path.exists(p):
             raise FileNotFoundError(
                 f"{p} is missing: build it with `make -C cfd_amd/csrc` (or __graft_entry__.build()); "
