@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--preset", choices=["cavity", "wind_tunnel"], default=None)
     ap.add_argument("--scheme", choices=["ab", "aa"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-slab", action="store_true",
+                    help="N = 1 only: run the z-slab code path of N > 1 (split step, RCCL ring to itself)")
     args = ap.parse_args()
 
     import torch
@@ -104,22 +106,29 @@ def main():
     car = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
     dist = None
-    if world > 1:
+    if world > 1 or args.rehearse_slab:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from cfd_amd import slab
         # two streams: boundary layers + RCCL on a side stream beside the interior update (3-4 % faster
         # than one stream whenever a rank has a neighbour, tools/rccl_self_probe.py)
         eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme, two_streams=True)
         solver = eng.solver
-        if args.config == 4:
-            solver.set_field_window(0, 4)
+        if scheme == lbm.SCHEME_AA:
+            # the in-place scheme writes rho/u of the field window in every split step: keep it small
+            solver.set_field_window(0, min(4, D))
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
         if obstacle:
             solver.load_mesh(car)   # device voxeliser: every slab casts the rays of its own layers
         drv.exchange_mask()
         drv.exchange_populations()
+        drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
         step = drv.step
     else:
         solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, scheme=scheme)

@@ -1608,6 +1608,21 @@ int lbm_set_field_window(lbm_ctx* c, int z_begin, int nz) {
     return LBM_OK;
 }
 
+int lbm_set_streams(lbm_ctx* c, void* stream, void* boundary_stream) {
+    NEED(c);
+    if (!stream) return fail(c, LBM_ERR_INVALID, "lbm_set_streams: stream is null");
+    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_set_streams: a split step is in flight");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream_b) HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    if (c->own_stream) {
+        HIPCHK(c, hipStreamDestroy(c->stream));
+        c->own_stream = false;
+    }
+    c->stream = (hipStream_t)stream;
+    c->stream_b = (hipStream_t)boundary_stream;
+    return LBM_OK;
+}
+
 int lbm_sync(lbm_ctx* c) {
     NEED(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lbm_step": ([_ctx, C.c_int], C.c_int),
     "lbm_compute_curl": ([_ctx], C.c_int),
     "lbm_sync": ([_ctx], C.c_int),
+    "lbm_set_streams": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_set_field_window": ([_ctx, C.c_int, C.c_int], C.c_int),
     "lbm_read_density": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_velocity": ([_ctx, _fp, C.c_size_t], C.c_int),

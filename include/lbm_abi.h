@@ -168,6 +168,14 @@ int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_c
  * needs the whole domain in the window.  No counterpart in the reference. */
 int lbm_set_field_window(lbm_ctx* ctx, int z_begin, int nz);
 
+/* Rebinds the context to other caller-owned streams (lbm_opts.stream / boundary_stream) after
+ * draining the current ones.  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+ * default); two streams that share a queue do not overlap, so a multi-GPU driver times a few steps
+ * on candidate streams and keeps the pair on which the boundary layers, the RCCL exchange and the
+ * interior update really run side by side (cfd_amd/slab.py: SlabSolver.autotune_streams).
+ * No counterpart in the reference (single default stream). */
+int lbm_set_streams(lbm_ctx* ctx, void* stream, void* boundary_stream);
+
 int lbm_get_dims(lbm_ctx* ctx, int* w, int* h, int* d);
 int lbm_get_stats(lbm_ctx* ctx, lbm_stats* out);
 int lbm_timer_begin(lbm_ctx* ctx);
