@@ -51,10 +51,29 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
         s.step(1)
         steps += 1
     dt = time.perf_counter() - t0
-    return {"value": round(W * H * D * steps / dt / 1e6, 2), "unit": "MLUPS", "cores": threads,
-            "kind": "port",
-            "sample": f"{W}x{H}x{D} {'cavity' if preset else 'wind tunnel'}{' + car' if obj else ''}, {steps} steps of oracle/lbm_oracle.c (OpenMP over z, "
-                      f"{threads} threads, -O2 -ffp-contract=off), {dt:.1f} s"}
+    out = {"value": round(W * H * D * steps / dt / 1e6, 2), "unit": "MLUPS", "cores": threads,
+           "kind": "port",
+           "sample": f"{W}x{H}x{D} {'cavity' if preset else 'wind tunnel'}{' + car' if obj else ''}, {steps} steps of oracle/lbm_oracle.c (OpenMP over z, "
+                     f"{threads} threads, -O2 -ffp-contract=off), {dt:.1f} s"}
+    # north_star's "single-threaded transliteration" figure beside it: the same code on one thread,
+    # on a 128 x 128 x 64 corner of the workload (about 4 s)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        del s
+        s1 = O.Solver(128, 128, 64, preset)
+        s1.init()
+        s1.step(1)
+        t0 = time.perf_counter()
+        n1 = 0
+        while n1 < 2 or (time.perf_counter() - t0 < 4.0 and n1 < 20):
+            s1.step(1)
+            n1 += 1
+        out["value_1_thread"] = round(128 * 128 * 64 * n1 / (time.perf_counter() - t0) / 1e6, 2)
+        out["sample_1_thread"] = f"128x128x64, {n1} steps, 1 thread"
+    except OSError:
+        pass
+    return out
 
 
 def main():
