@@ -1,0 +1,337 @@
+// k_step.h -- geometry, boundary classification and the fused stream-collide kernel (A/B pull scheme).
+// Part of the single translation unit lbm_hip.hip (included inside its anonymous namespace, after
+// <hip/hip_runtime.h>, include/lbm_abi.h and d3q19.h); not a stand-alone header.
+// ------------------------------------------------------------------------------------------
+// geometry shared by host and device
+// ------------------------------------------------------------------------------------------
+struct Geo {
+    int W, H, D;        // owned extent of this context
+    int Dg, z0;         // global depth, global z of owned layer 0
+    int slab;           // 1: one z-slab of a taller domain (ghost layers are fed by the halo exchange)
+    int fz0, fnz;       // field window: rho/u are kept for owned layers [fz0, fz0+fnz) only
+    int Wp;             // floats per row of one population (multiple of 32: rows start on 128-byte lines)
+    int Wm;             // 64-bit mask words per row
+    int Wt;             // 64-cell tiles per row (= Wm)
+    long long row;      // floats between consecutive y rows of one population
+    long long layer;    // floats between consecutive z layers of one population
+    long long plane;    // floats between consecutive populations of one cell
+    long long mlayer;   // floats per population layer inside a halo message (H*Wp)
+};
+// Two layouts share every kernel through these strides:
+//   LBM_LAYOUT_PLANES  [k][z][y][x] : row = Wp,    layer = rows*Wp,  plane = (D+2)*layer + skew
+//   LBM_LAYOUT_ROWS    [z][y][k][x] : plane = Wp,  row = 19*Wp,      layer = rows*row
+// In the row-interleaved form the 19 runs of one (y,z) row are one contiguous 19*Wp*4-byte chunk:
+// a step writes whole chunks and reads 1-3 KB pieces of nine neighbouring chunks, which streams
+// 6-7 % faster from HBM than 19+19 far-apart planes (profiles/r01_tuning.md, tools/membench5/6).
+
+struct Params {
+    float U, omega_shear, omega_bulk;
+};
+
+// device address of cell (x, y, zl) inside a plane; zl = local layer index incl. ghost (owned: 1..D)
+__device__ __forceinline__ long long cell_off(const Geo& g, int x, int y, int zl) {
+    return (long long)zl * g.layer + (long long)y * g.row + x;
+}
+
+// flat thread index of the 1-D kernels.  A dispatch holds at most 2^32 - 1 work-items per grid
+// dimension, and a buffer sized to HBM has more floats than that, so those kernels are launched on
+// the 2-D grid of grid1() and flatten it here.
+__device__ __forceinline__ long long gidx() {
+    return ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+}
+
+__device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long* __restrict__ mask,
+                                         int x, int y, int zl) {
+    const unsigned long long w = mask[((long long)zl * g.H + y) * g.Wm + (x >> 6)];
+    return (w >> (x & 63)) & 1ull;
+}
+
+// Populations whose A/B fast-path load is non-temporal when TUNE bit 0 is set (bit k = population k).
+// Default: the ten x-shifted populations keep the default policy -- their misaligned loads touch a
+// second 128-byte line that the neighbouring wave needs too; nt would drop it after one use
+// (+2 % at 256^3, tools/tune_bench.py).
+#ifndef LBM_NT_SET
+#define LBM_NT_SET 0x78079u   // cx == 0: k = 0, 3, 4, 5, 6, 15, 16, 17, 18
+#endif
+// population load / store with an explicit cache policy (TUNE bit 0: nt loads, bit 1: sc1 stores)
+template <int TUNE>
+__device__ __forceinline__ float ldf(const float* p) {
+    return (TUNE & 1) ? __builtin_nontemporal_load(p) : *p;
+}
+template <int TUNE, int K>
+__device__ __forceinline__ float ldk(const float* p) {
+    return ((TUNE & 1) && ((LBM_NT_SET >> K) & 1u)) ? __builtin_nontemporal_load(p) : *p;
+}
+template <int TUNE>
+__device__ __forceinline__ void stf(float* p, float v) {
+    if (TUNE & 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+    else __builtin_nontemporal_store(v, p);
+}
+
+// Which branch of the reference chain (lbm_solver.cu:283-318) feeds direction K of the fluid cell
+// (x, y, zl).  Single source of truth for the step kernel, the moment kernel and
+// lbm_read_classification.
+// `nb_solid()` answers "is the cell this direction pulls from solid?"; it is only asked when that
+// cell exists.
+template <int PRESET, int K, class NbSolid>
+__device__ __forceinline__ unsigned classify_with(const Geo& g, int x, int y, int zl, NbSolid nb_solid) {
+    constexpr int cx = CX[K], cy = CY[K], cz = CZ[K];
+    const int nx = x - cx, ny = y - cy;
+    const int nzg = (zl - 1) + g.z0 - cz;
+    if (PRESET == LBM_PRESET_CAVITY) {
+        if (cy == -1 && ny >= g.H) return SRC_LID_BB;
+        if ((cx == 1 && nx < 0) || (cx == -1 && nx >= g.W) || (cy == 1 && ny < 0) ||
+            (cz != 0 && (nzg < 0 || nzg >= g.Dg)))
+            return SRC_WALL_BB;
+    } else {
+        if (cx == 1 && nx < 0) return SRC_INLET;
+        if (cx == -1 && nx >= g.W) return SRC_OUTLET;
+        if (cy == 1 && ny < 0) return SRC_FLOOR_BB;
+        if (cy == -1 && ny >= g.H) return SRC_CEIL_RFY;
+        if (cz != 0 && (nzg < 0 || nzg >= g.Dg)) return SRC_SIDE_RFZ;
+    }
+    if (K == 0) return SRC_PULL;
+    return nb_solid() ? SRC_SOLID_BB : SRC_PULL;
+}
+
+// per-cell form: the neighbour's bit is read from the packed mask in memory
+template <int PRESET, int K>
+__device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                 int x, int y, int zl) {
+    return classify_with<PRESET, K>(g, x, y, zl, [&] { return solid_at(g, mask, x - CX[K], y - CY[K], zl - CZ[K]); });
+}
+
+// Per-tile form used by the step kernels: the solid bits of the 3 x 3 rows around one 64-cell
+// tile are fetched ONCE into wave-uniform registers (scalar loads), so the 19 directions are
+// classified without a memory round trip each and the 19 population loads issue back to back.
+struct TileMask {
+    unsigned long long w[3][3];  // [dz+1][dy+1]: cells x0 .. x0+63 of row (y+dy, zl+dz); 0 where that row does not exist
+    unsigned left, right;        // bit 3*(dz+1)+(dy+1): cell x0-1 / x0+64 of the same row
+};
+__device__ __forceinline__ TileMask load_tile_mask(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                   int xs, int y, int zl) {
+    TileMask t;
+    t.left = 0; t.right = 0;
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            const bool ok = yy >= 0 && yy < g.H;  // layers zl-1 .. zl+1 always exist (ghost layers)
+            const unsigned long long* r = mask + ((long long)(zl + dz) * g.H + (ok ? yy : y)) * g.Wm;
+            const unsigned long long w = r[xs];
+            const unsigned long long wl = r[xs > 0 ? xs - 1 : xs];
+            const unsigned long long wr = r[xs + 1 < g.Wm ? xs + 1 : xs];
+            t.w[dz + 1][dy + 1] = ok ? w : 0ull;
+            const int bit = 3 * (dz + 1) + (dy + 1);
+            if (ok && xs > 0) t.left |= (unsigned)(wl >> 63) << bit;
+            if (ok && xs + 1 < g.Wm) t.right |= (unsigned)(wr & 1ull) << bit;
+        }
+    return t;
+}
+template <int K>
+__device__ __forceinline__ bool tile_nb_solid(const TileMask& t, int lane) {
+    constexpr int iz = 1 - CZ[K], iy = 1 - CY[K], bit = 3 * iz + iy;
+    unsigned long long w = t.w[iz][iy];
+    if (CX[K] == 1) w = (w << 1) | (unsigned long long)((t.left >> bit) & 1u);           // neighbour x-1
+    if (CX[K] == -1) w = (w >> 1) | ((unsigned long long)((t.right >> bit) & 1u) << 63);  // neighbour x+1
+    return (w >> lane) & 1ull;
+}
+
+// Outlet branch (lbm_solver.cu:292-296): the reference indexes f_in[k*n + nz*W*H + ny*W + (W-1)]
+// without range-checking ny/nz, so a row off the y end carries into the next z layer and a layer
+// off the z end carries into the neighbouring population plane (quirk Q2).  Our planes are padded,
+// so the carry is applied in logical coordinates.
+template <int K>
+__device__ __forceinline__ long long outlet_off(const Geo& g, int y, int zl) {
+    int pl = K;
+    int ny = y - CY[K];
+    int nzg = (zl - 1) + g.z0 - CZ[K];
+    if (ny < 0) { ny += g.H; nzg -= 1; }
+    else if (ny >= g.H) { ny -= g.H; nzg += 1; }
+    // An undecomposed domain holds the wrapped layer itself; a slab finds it in its ghost layer,
+    // where the ring halo exchange put the neighbour's values (see k_halo_unpack).
+    if (nzg < 0) { pl -= 1; if (!g.slab) nzg += g.Dg; }
+    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nzg -= g.Dg; }
+    const int nzl = nzg - g.z0 + 1;
+    return (long long)pl * g.plane + cell_off(g, g.W - 1, ny, nzl);
+}
+template <int K>
+__device__ __forceinline__ float outlet_read(const Geo& g, const float* __restrict__ fin, int y, int zl) {
+    return fin[outlet_off<K>(g, y, zl)];
+}
+
+// full boundary chain for one direction, per lane: the branch is turned into an address by
+// selects, so every lane issues exactly one load and no load waits for another
+template <int PRESET, int K>
+__device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
+                                                int lane, int x, int y, int zl, long long own, float inlet_e, float U) {
+    const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
+    // own-cell sources: ceiling / side mirror, bounce-back (floor, solid, wall, lid); an inlet lane
+    // loads its own slot and discards it
+    const int pl = code == SRC_CEIL_RFY ? RFY[K] : (code == SRC_SIDE_RFZ ? RFZ[K] : (code == SRC_INLET ? K : INV[K]));
+    long long a = (long long)pl * g.plane + own;
+    if (code == SRC_PULL) a = (long long)K * g.plane + own - ((long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K]);
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) {
+        const long long ao = outlet_off<K>(g, y, zl);  // wave-uniform
+        if (code == SRC_OUTLET) a = ao;
+    }
+    float v = fin[a];
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == 1 && code == SRC_INLET) v = weight(K) * inlet_e;
+    if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
+    return v;
+}
+
+// interior tile: rows y-1..y+1 and layers z-1..z+1 exist, no solid cell within reach; only the
+// x ends of the row need care.
+template <int PRESET, int K, int TUNE>
+__device__ __forceinline__ float gather_fast(const Geo& g, const float* __restrict__ fin,
+                                             int x, int y, int zl, long long own, float inlet_e) {
+    constexpr int cx = CX[K];
+    const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
+                       (long long)(y - CY[K]) * g.row;
+    if (cx == 0) return ldk<TUNE, K>(row + x);
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
+        if (cx == 1) {
+            const float v = ldk<TUNE, K>(row + x - 1);  // x = 0 reads the pad/previous row: in bounds, discarded
+            return x == 0 ? weight(K) * inlet_e : v;
+        }
+        const int xs = x + 1 < g.W ? x + 1 : g.W - 1;  // outlet: copy from x = W-1 (ny, nz in range here)
+        return ldk<TUNE, K>(row + xs);
+    } else {
+        const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
+        const float* p = wall ? fin + (long long)INV[K] * g.plane + own : row + x - cx;  // one load either way
+        return ldk<TUNE, K>(p);
+    }
+}
+
+template <int PRESET, int K>
+struct GatherAll {
+    template <int TUNE>
+    static __device__ __forceinline__ void fast(const Geo& g, const float* __restrict__ fin, int x, int y,
+                                                int zl, long long own, float inlet_e, float* f) {
+        GatherAll<PRESET, K - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
+        f[K] = gather_fast<PRESET, K, TUNE>(g, fin, x, y, zl, own, inlet_e);
+    }
+    static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
+                                                   int lane, int x, int y, int zl, long long own, float inlet_e,
+                                                   float U, float* f) {
+        GatherAll<PRESET, K - 1>::general(g, fin, t, lane, x, y, zl, own, inlet_e, U, f);
+        f[K] = gather_general<PRESET, K>(g, fin, t, lane, x, y, zl, own, inlet_e, U);
+    }
+    static __device__ __forceinline__ void classify(const Geo& g, const unsigned long long* __restrict__ mask,
+                                                    int x, int y, int zl, unsigned char* out) {
+        GatherAll<PRESET, K - 1>::classify(g, mask, x, y, zl, out);
+        out[K] = (unsigned char)classify_dir<PRESET, K>(g, mask, x, y, zl);
+    }
+};
+template <int PRESET>
+struct GatherAll<PRESET, -1> {
+    template <int TUNE>
+    static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
+    static __device__ __forceinline__ void general(const Geo&, const float*, const TileMask&, int, int, int, int,
+                                                   long long, float, float, float*) {}
+    static __device__ __forceinline__ void classify(const Geo&, const unsigned long long*, int, int, int,
+                                                    unsigned char*) {}
+};
+
+// Tile -> (xs, y, z) mapping shared by the kernels that walk tiles: a 256-thread block is four
+// waves; `segsx` of them sit side by side in x, the rest stack in y.
+struct TileId {
+    int xs, y, lane;
+};
+__device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileId t;
+    t.lane = threadIdx.x & 63;
+    const int segsx = 1 << segsx_log2;
+    t.xs = blockIdx.x * segsx + (wave & (segsx - 1));
+    t.y = blockIdx.y * (4 >> segsx_log2) + (wave >> segsx_log2);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
+// MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
+// MODE 2: step of the one or two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
+//         that also writes the outgoing halo messages, so no separate pack pass is needed.
+// ------------------------------------------------------------------------------------------
+// message layout: see k_halo_pack
+__device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
+                                          const float* v) {
+    const long long at = (long long)y * g.Wp + x;
+#pragma unroll
+    for (int j = 0; j < 5; j++) msg[(long long)j * g.mlayer + at] = v[side ? UP5[j] : DOWN5[j]];
+    if (x != g.W - 1) return;
+    float* tail = msg + 5 * g.mlayer;
+    if (side) {
+        if (y == g.H - 1) { tail[0] = v[10]; tail[1] = v[9]; }
+        tail[2 + y] = v[13];
+    } else if (y == 0) {
+        tail[0] = v[8];
+        tail[1] = v[9];
+    }
+}
+
+template <int PRESET, int MODE, int TUNE>
+__global__ __launch_bounds__(256) void k_stream_collide(
+    const float* __restrict__ fin, float* __restrict__ fout,
+    const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
+    float* __restrict__ rho_out, float4* __restrict__ u_out,
+    Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
+    int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top) {
+    const TileId t = tile_of_wave(segsx_log2);
+    const int y = t.y;
+    // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
+    // starts on the layers the previous step wrote last (still in the Infinity Cache)
+    const int zl = MODE == 2 ? (blockIdx.z == 0 ? zl_begin : zl_second)
+                             : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    if (t.xs >= g.Wt || y >= g.H) return;
+    const int x = t.xs * 64 + t.lane;
+    const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
+    if (x >= g.W) return;
+    if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
+
+    const long long own = cell_off(g, x, y, zl);
+    const float inlet_e = inlet_bracket(p.U);
+    float f[Q];
+
+    if (flag == 0) {
+        GatherAll<PRESET, Q - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
+    } else {
+        const TileMask tm = load_tile_mask(g, mask, t.xs, y, zl);
+        if ((tm.w[1][1] >> t.lane) & 1ull) {
+            // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
+            // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
+            if (MODE == 1) {
+                const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
+                rho_out[ridx] = 0.0f;
+                u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
+                for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
+                if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
+                if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
+            }
+            return;
+        }
+        GatherAll<PRESET, Q - 1>::general(g, fin, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
+    }
+
+    const Moments m = moments_of(f);
+    if (MODE == 1) {
+        const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
+        rho_out[ridx] = m.rho;
+        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
+        return;
+    }
+    float o[Q];
+    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
+    float* dst = fout + own;
+#pragma unroll
+    for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
+    if (MODE == 2) {
+        if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, o);
+        if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, o);
+    }
+}

@@ -35,1018 +35,13 @@ using namespace d3q19;
 
 namespace {
 
-// ------------------------------------------------------------------------------------------
-// geometry shared by host and device
-// ------------------------------------------------------------------------------------------
-struct Geo {
-    int W, H, D;        // owned extent of this context
-    int Dg, z0;         // global depth, global z of owned layer 0
-    int slab;           // 1: one z-slab of a taller domain (ghost layers are fed by the halo exchange)
-    int fz0, fnz;       // field window: rho/u are kept for owned layers [fz0, fz0+fnz) only
-    int Wp;             // floats per row of one population (multiple of 32: rows start on 128-byte lines)
-    int Wm;             // 64-bit mask words per row
-    int Wt;             // 64-cell tiles per row (= Wm)
-    long long row;      // floats between consecutive y rows of one population
-    long long layer;    // floats between consecutive z layers of one population
-    long long plane;    // floats between consecutive populations of one cell
-    long long mlayer;   // floats per population layer inside a halo message (H*Wp)
-};
-// Two layouts share every kernel through these strides:
-//   LBM_LAYOUT_PLANES  [k][z][y][x] : row = Wp,    layer = rows*Wp,  plane = (D+2)*layer + skew
-//   LBM_LAYOUT_ROWS    [z][y][k][x] : plane = Wp,  row = 19*Wp,      layer = rows*row
-// In the row-interleaved form the 19 runs of one (y,z) row are one contiguous 19*Wp*4-byte chunk:
-// a step writes whole chunks and reads 1-3 KB pieces of nine neighbouring chunks, which streams
-// 6-7 % faster from HBM than 19+19 far-apart planes (profiles/r01_tuning.md, tools/membench5/6).
-
-struct Params {
-    float U, omega_shear, omega_bulk;
-};
-
-// device address of cell (x, y, zl) inside a plane; zl = local layer index incl. ghost (owned: 1..D)
-__device__ __forceinline__ long long cell_off(const Geo& g, int x, int y, int zl) {
-    return (long long)zl * g.layer + (long long)y * g.row + x;
-}
-
-// flat thread index of the 1-D kernels.  A dispatch holds at most 2^32 - 1 work-items per grid
-// dimension, and a buffer sized to HBM has more floats than that, so those kernels are launched on
-// the 2-D grid of grid1() and flatten it here.
-__device__ __forceinline__ long long gidx() {
-    return ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-}
-
-__device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long* __restrict__ mask,
-                                         int x, int y, int zl) {
-    const unsigned long long w = mask[((long long)zl * g.H + y) * g.Wm + (x >> 6)];
-    return (w >> (x & 63)) & 1ull;
-}
-
-// Populations whose A/B fast-path load is non-temporal when TUNE bit 0 is set (bit k = population k).
-// Default: the ten x-shifted populations keep the default policy -- their misaligned loads touch a
-// second 128-byte line that the neighbouring wave needs too; nt would drop it after one use
-// (+2 % at 256^3, tools/tune_bench.py).
-#ifndef LBM_NT_SET
-#define LBM_NT_SET 0x78079u   // cx == 0: k = 0, 3, 4, 5, 6, 15, 16, 17, 18
-#endif
-// population load / store with an explicit cache policy (TUNE bit 0: nt loads, bit 1: sc1 stores)
-template <int TUNE>
-__device__ __forceinline__ float ldf(const float* p) {
-    return (TUNE & 1) ? __builtin_nontemporal_load(p) : *p;
-}
-template <int TUNE, int K>
-__device__ __forceinline__ float ldk(const float* p) {
-    return ((TUNE & 1) && ((LBM_NT_SET >> K) & 1u)) ? __builtin_nontemporal_load(p) : *p;
-}
-template <int TUNE>
-__device__ __forceinline__ void stf(float* p, float v) {
-    if (TUNE & 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
-    else __builtin_nontemporal_store(v, p);
-}
-
-// Which branch of the reference chain (lbm_solver.cu:283-318) feeds direction K of the fluid cell
-// (x, y, zl).  Single source of truth for the step kernel, the moment kernel and
-// lbm_read_classification.
-// `nb_solid()` answers "is the cell this direction pulls from solid?"; it is only asked when that
-// cell exists.
-template <int PRESET, int K, class NbSolid>
-__device__ __forceinline__ unsigned classify_with(const Geo& g, int x, int y, int zl, NbSolid nb_solid) {
-    constexpr int cx = CX[K], cy = CY[K], cz = CZ[K];
-    const int nx = x - cx, ny = y - cy;
-    const int nzg = (zl - 1) + g.z0 - cz;
-    if (PRESET == LBM_PRESET_CAVITY) {
-        if (cy == -1 && ny >= g.H) return SRC_LID_BB;
-        if ((cx == 1 && nx < 0) || (cx == -1 && nx >= g.W) || (cy == 1 && ny < 0) ||
-            (cz != 0 && (nzg < 0 || nzg >= g.Dg)))
-            return SRC_WALL_BB;
-    } else {
-        if (cx == 1 && nx < 0) return SRC_INLET;
-        if (cx == -1 && nx >= g.W) return SRC_OUTLET;
-        if (cy == 1 && ny < 0) return SRC_FLOOR_BB;
-        if (cy == -1 && ny >= g.H) return SRC_CEIL_RFY;
-        if (cz != 0 && (nzg < 0 || nzg >= g.Dg)) return SRC_SIDE_RFZ;
-    }
-    if (K == 0) return SRC_PULL;
-    return nb_solid() ? SRC_SOLID_BB : SRC_PULL;
-}
-
-// per-cell form: the neighbour's bit is read from the packed mask in memory
-template <int PRESET, int K>
-__device__ __forceinline__ unsigned classify_dir(const Geo& g, const unsigned long long* __restrict__ mask,
-                                                 int x, int y, int zl) {
-    return classify_with<PRESET, K>(g, x, y, zl, [&] { return solid_at(g, mask, x - CX[K], y - CY[K], zl - CZ[K]); });
-}
-
-// Per-tile form used by the step kernels: the solid bits of the 3 x 3 rows around one 64-cell
-// tile are fetched ONCE into wave-uniform registers (scalar loads), so the 19 directions are
-// classified without a memory round trip each and the 19 population loads issue back to back.
-struct TileMask {
-    unsigned long long w[3][3];  // [dz+1][dy+1]: cells x0 .. x0+63 of row (y+dy, zl+dz); 0 where that row does not exist
-    unsigned left, right;        // bit 3*(dz+1)+(dy+1): cell x0-1 / x0+64 of the same row
-};
-__device__ __forceinline__ TileMask load_tile_mask(const Geo& g, const unsigned long long* __restrict__ mask,
-                                                   int xs, int y, int zl) {
-    TileMask t;
-    t.left = 0; t.right = 0;
-#pragma unroll
-    for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++) {
-            const int yy = y + dy;
-            const bool ok = yy >= 0 && yy < g.H;  // layers zl-1 .. zl+1 always exist (ghost layers)
-            const unsigned long long* r = mask + ((long long)(zl + dz) * g.H + (ok ? yy : y)) * g.Wm;
-            const unsigned long long w = r[xs];
-            const unsigned long long wl = r[xs > 0 ? xs - 1 : xs];
-            const unsigned long long wr = r[xs + 1 < g.Wm ? xs + 1 : xs];
-            t.w[dz + 1][dy + 1] = ok ? w : 0ull;
-            const int bit = 3 * (dz + 1) + (dy + 1);
-            if (ok && xs > 0) t.left |= (unsigned)(wl >> 63) << bit;
-            if (ok && xs + 1 < g.Wm) t.right |= (unsigned)(wr & 1ull) << bit;
-        }
-    return t;
-}
-template <int K>
-__device__ __forceinline__ bool tile_nb_solid(const TileMask& t, int lane) {
-    constexpr int iz = 1 - CZ[K], iy = 1 - CY[K], bit = 3 * iz + iy;
-    unsigned long long w = t.w[iz][iy];
-    if (CX[K] == 1) w = (w << 1) | (unsigned long long)((t.left >> bit) & 1u);           // neighbour x-1
-    if (CX[K] == -1) w = (w >> 1) | ((unsigned long long)((t.right >> bit) & 1u) << 63);  // neighbour x+1
-    return (w >> lane) & 1ull;
-}
-
-// Outlet branch (lbm_solver.cu:292-296): the reference indexes f_in[k*n + nz*W*H + ny*W + (W-1)]
-// without range-checking ny/nz, so a row off the y end carries into the next z layer and a layer
-// off the z end carries into the neighbouring population plane (quirk Q2).  Our planes are padded,
-// so the carry is applied in logical coordinates.
-template <int K>
-__device__ __forceinline__ long long outlet_off(const Geo& g, int y, int zl) {
-    int pl = K;
-    int ny = y - CY[K];
-    int nzg = (zl - 1) + g.z0 - CZ[K];
-    if (ny < 0) { ny += g.H; nzg -= 1; }
-    else if (ny >= g.H) { ny -= g.H; nzg += 1; }
-    // An undecomposed domain holds the wrapped layer itself; a slab finds it in its ghost layer,
-    // where the ring halo exchange put the neighbour's values (see k_halo_unpack).
-    if (nzg < 0) { pl -= 1; if (!g.slab) nzg += g.Dg; }
-    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nzg -= g.Dg; }
-    const int nzl = nzg - g.z0 + 1;
-    return (long long)pl * g.plane + cell_off(g, g.W - 1, ny, nzl);
-}
-template <int K>
-__device__ __forceinline__ float outlet_read(const Geo& g, const float* __restrict__ fin, int y, int zl) {
-    return fin[outlet_off<K>(g, y, zl)];
-}
-
-// full boundary chain for one direction, per lane: the branch is turned into an address by
-// selects, so every lane issues exactly one load and no load waits for another
-template <int PRESET, int K>
-__device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
-                                                int lane, int x, int y, int zl, long long own, float inlet_e, float U) {
-    const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
-    // own-cell sources: ceiling / side mirror, bounce-back (floor, solid, wall, lid); an inlet lane
-    // loads its own slot and discards it
-    const int pl = code == SRC_CEIL_RFY ? RFY[K] : (code == SRC_SIDE_RFZ ? RFZ[K] : (code == SRC_INLET ? K : INV[K]));
-    long long a = (long long)pl * g.plane + own;
-    if (code == SRC_PULL) a = (long long)K * g.plane + own - ((long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K]);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) {
-        const long long ao = outlet_off<K>(g, y, zl);  // wave-uniform
-        if (code == SRC_OUTLET) a = ao;
-    }
-    float v = fin[a];
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == 1 && code == SRC_INLET) v = weight(K) * inlet_e;
-    if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
-    return v;
-}
-
-// interior tile: rows y-1..y+1 and layers z-1..z+1 exist, no solid cell within reach; only the
-// x ends of the row need care.
-template <int PRESET, int K, int TUNE>
-__device__ __forceinline__ float gather_fast(const Geo& g, const float* __restrict__ fin,
-                                             int x, int y, int zl, long long own, float inlet_e) {
-    constexpr int cx = CX[K];
-    const float* row = fin + (long long)K * g.plane + (long long)(zl - CZ[K]) * g.layer +
-                       (long long)(y - CY[K]) * g.row;
-    if (cx == 0) return ldk<TUNE, K>(row + x);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
-        if (cx == 1) {
-            const float v = ldk<TUNE, K>(row + x - 1);  // x = 0 reads the pad/previous row: in bounds, discarded
-            return x == 0 ? weight(K) * inlet_e : v;
-        }
-        const int xs = x + 1 < g.W ? x + 1 : g.W - 1;  // outlet: copy from x = W-1 (ny, nz in range here)
-        return ldk<TUNE, K>(row + xs);
-    } else {
-        const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
-        const float* p = wall ? fin + (long long)INV[K] * g.plane + own : row + x - cx;  // one load either way
-        return ldk<TUNE, K>(p);
-    }
-}
-
-template <int PRESET, int K>
-struct GatherAll {
-    template <int TUNE>
-    static __device__ __forceinline__ void fast(const Geo& g, const float* __restrict__ fin, int x, int y,
-                                                int zl, long long own, float inlet_e, float* f) {
-        GatherAll<PRESET, K - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
-        f[K] = gather_fast<PRESET, K, TUNE>(g, fin, x, y, zl, own, inlet_e);
-    }
-    static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
-                                                   int lane, int x, int y, int zl, long long own, float inlet_e,
-                                                   float U, float* f) {
-        GatherAll<PRESET, K - 1>::general(g, fin, t, lane, x, y, zl, own, inlet_e, U, f);
-        f[K] = gather_general<PRESET, K>(g, fin, t, lane, x, y, zl, own, inlet_e, U);
-    }
-    static __device__ __forceinline__ void classify(const Geo& g, const unsigned long long* __restrict__ mask,
-                                                    int x, int y, int zl, unsigned char* out) {
-        GatherAll<PRESET, K - 1>::classify(g, mask, x, y, zl, out);
-        out[K] = (unsigned char)classify_dir<PRESET, K>(g, mask, x, y, zl);
-    }
-};
-template <int PRESET>
-struct GatherAll<PRESET, -1> {
-    template <int TUNE>
-    static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
-    static __device__ __forceinline__ void general(const Geo&, const float*, const TileMask&, int, int, int, int,
-                                                   long long, float, float, float*) {}
-    static __device__ __forceinline__ void classify(const Geo&, const unsigned long long*, int, int, int,
-                                                    unsigned char*) {}
-};
-
-// Tile -> (xs, y, z) mapping shared by the kernels that walk tiles: a 256-thread block is four
-// waves; `segsx` of them sit side by side in x, the rest stack in y.
-struct TileId {
-    int xs, y, lane;
-};
-__device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    TileId t;
-    t.lane = threadIdx.x & 63;
-    const int segsx = 1 << segsx_log2;
-    t.xs = blockIdx.x * segsx + (wave & (segsx - 1));
-    t.y = blockIdx.y * (4 >> segsx_log2) + (wave >> segsx_log2);
-    return t;
-}
-
-// ------------------------------------------------------------------------------------------
-// the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
-// MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
-// MODE 2: step of the one or two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
-//         that also writes the outgoing halo messages, so no separate pack pass is needed.
-// ------------------------------------------------------------------------------------------
-// message layout: see k_halo_pack
-__device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
-                                          const float* v) {
-    const long long at = (long long)y * g.Wp + x;
-#pragma unroll
-    for (int j = 0; j < 5; j++) msg[(long long)j * g.mlayer + at] = v[side ? UP5[j] : DOWN5[j]];
-    if (x != g.W - 1) return;
-    float* tail = msg + 5 * g.mlayer;
-    if (side) {
-        if (y == g.H - 1) { tail[0] = v[10]; tail[1] = v[9]; }
-        tail[2 + y] = v[13];
-    } else if (y == 0) {
-        tail[0] = v[8];
-        tail[1] = v[9];
-    }
-}
-
-template <int PRESET, int MODE, int TUNE>
-__global__ __launch_bounds__(256) void k_stream_collide(
-    const float* __restrict__ fin, float* __restrict__ fout,
-    const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
-    float* __restrict__ rho_out, float4* __restrict__ u_out,
-    Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
-    int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top) {
-    const TileId t = tile_of_wave(segsx_log2);
-    const int y = t.y;
-    // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
-    // starts on the layers the previous step wrote last (still in the Infinity Cache)
-    const int zl = MODE == 2 ? (blockIdx.z == 0 ? zl_begin : zl_second)
-                             : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
-    if (t.xs >= g.Wt || y >= g.H) return;
-    const int x = t.xs * 64 + t.lane;
-    const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
-    if (x >= g.W) return;
-    if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
-
-    const long long own = cell_off(g, x, y, zl);
-    const float inlet_e = inlet_bracket(p.U);
-    float f[Q];
-
-    if (flag == 0) {
-        GatherAll<PRESET, Q - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
-    } else {
-        const TileMask tm = load_tile_mask(g, mask, t.xs, y, zl);
-        if ((tm.w[1][1] >> t.lane) & 1ull) {
-            // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
-            // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
-            if (MODE == 1) {
-                const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
-                rho_out[ridx] = 0.0f;
-                u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
-                for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
-                if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
-                if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
-            }
-            return;
-        }
-        GatherAll<PRESET, Q - 1>::general(g, fin, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
-    }
-
-    const Moments m = moments_of(f);
-    if (MODE == 1) {
-        const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
-        rho_out[ridx] = m.rho;
-        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
-        return;
-    }
-    float o[Q];
-    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
-    float* dst = fout + own;
-#pragma unroll
-    for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
-    if (MODE == 2) {
-        if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, o);
-        if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, o);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// AA-pattern variant: ONE population buffer updated in place (half the memory of A/B).
-//
-// Let F_k(c) be the post-collision population k of cell c (what the A/B buffer holds).  The
-// single buffer M stores it in one of two layouts, alternating every step:
-//   after an ODD  step ("streamed"):  F_k(c) lives at M[k][c + c_k]
-//   after an EVEN step ("swapped"):   F_k(c) lives at M[inv k][c]
-// so an even step reads its own cell's slots and writes its own cell's slots, and an odd step
-// reads the neighbours' slots and writes exactly the slots it read.  Every branch of the
-// reference's boundary chain asks for some F_kk(cell) and is translated through the layout of the
-// moment; bounce-back and free-slip values sit in the solid neighbour's / the ghost shell's slots,
-// which no other thread touches, so the update is race-free.  The one exception is the outlet
-// branch (lbm_solver.cu:292-296), which copies from another FLUID cell of the x = W-1 column and
-// would race in place: those seven planes of that column are mirrored in a small double-buffered
-// side array `ob` that x = W-1 cells write each step and read the step after.
-// The buffer needs a ghost shell in x and y as well: Wp >= W+2 and H+2 rows per layer, addressed
-// linearly (x = -1 is the last pad slot of the previous row, y = -1 the last row of the previous
-// layer), which keeps x = 0 on a 128-byte boundary.
-// ------------------------------------------------------------------------------------------
-constexpr int OB_N = 7;
-constexpr int OB_PLANE[OB_N] = {2, 8, 9, 10, 12, 13, 14};
-__host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <= 10 ? pl - 7 : pl - 8); }
-// side-array slot of plane-slot i, local layer z in [-1, D] (ghost rows for the z-slab halo), row y
-__device__ __forceinline__ long long ob_at(const Geo& g, int i, int z, int y) {
-    return ((long long)i * (g.D + 2) + (z + 1)) * g.H + y;
-}
-
-template <int K>
-__device__ __forceinline__ long long dir_off(const Geo& g) {
-    return (long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K];
-}
-
-// where F_KK(own cell) is stored in the layout that PHASE reads
-template <int KK, int PHASE>
-__device__ __forceinline__ const float* aa_own_pop(const Geo& g, const float* M, long long own) {
-    return PHASE == 0 ? M + (long long)KK * g.plane + own + dir_off<KK>(g)   // streamed layout
-                      : M + (long long)INV[KK] * g.plane + own;             // swapped layout
-}
-// where F_K(own - c_K), the plainly pulled population, is stored
-template <int K, int PHASE>
-__device__ __forceinline__ const float* aa_pull_pop(const Geo& g, const float* M, long long own) {
-    return PHASE == 0 ? M + (long long)K * g.plane + own
-                      : M + (long long)INV[K] * g.plane + own - dir_off<K>(g);
-}
-
-template <int K>
-__device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __restrict__ ob_old, int y, int zl) {
-    int pl = K;
-    int ny = y - CY[K];
-    int nz = (zl - 1) - CZ[K];
-    if (ny < 0) { ny += g.H; nz -= 1; }
-    else if (ny >= g.H) { ny -= g.H; nz += 1; }
-    // as outlet_off(): an undecomposed domain wraps to its own far layer, a slab finds the
-    // neighbour's (or, over the ring link, the far rank's) column in its ghost row
-    const int nzg = nz + g.z0;
-    if (nzg < 0) { pl -= 1; if (!g.slab) nz += g.D; }
-    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nz -= g.D; }
-    return ob_old[ob_at(g, ob_index(pl), nz, ny)];
-}
-
-template <int PRESET, int K, int PHASE>
-__device__ __forceinline__ float aa_gather_general(const Geo& g, const float* M, const float* __restrict__ ob_old,
-                                                   const TileMask& t, int lane, int x, int y,
-                                                   int zl, long long own, float inlet_e, float U) {
-    const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
-    if (code == SRC_INLET) return weight(K) * inlet_e;
-    if (code == SRC_OUTLET) return aa_outlet_read<K>(g, ob_old, y, zl);
-    const float* p;
-    if (code == SRC_PULL) p = aa_pull_pop<K, PHASE>(g, M, own);
-    else if (code == SRC_CEIL_RFY) p = aa_own_pop<RFY[K], PHASE>(g, M, own);
-    else if (code == SRC_SIDE_RFZ) p = aa_own_pop<RFZ[K], PHASE>(g, M, own);
-    else p = aa_own_pop<INV[K], PHASE>(g, M, own);
-    float v = *p;
-    if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
-    return v;
-}
-
-template <int PRESET, int K, int PHASE, int TUNE>
-__device__ __forceinline__ float aa_gather_fast(const Geo& g, const float* M, const float* __restrict__ ob_old,
-                                                int x, int y, int zl, long long own, float inlet_e) {
-    constexpr int cx = CX[K];
-    const float* p = aa_pull_pop<K, PHASE>(g, M, own);
-    if (cx == 0) return ldf<TUNE>(p);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
-        if (cx == 1) {
-            const float v = ldf<TUNE>(p);  // x = 0 reads a ghost slot: in bounds, discarded
-            return x == 0 ? weight(K) * inlet_e : v;
-        }
-        if (x == g.W - 1)  // interior tile: ny, nz are in range
-            return ob_old[ob_at(g, ob_index(K), zl - 1 - CZ[K], y - CY[K])];
-        return ldf<TUNE>(p);
-    } else {
-        const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
-        if (wall) return *aa_own_pop<INV[K], PHASE>(g, M, own);
-        return ldf<TUNE>(p);
-    }
-}
-
-template <int PRESET, int PHASE, int TUNE, int K>
-struct AaGather {
-    static __device__ __forceinline__ void fast(const Geo& g, const float* M, const float* ob, int x, int y, int zl,
-                                                long long own, float e, float* f) {
-        AaGather<PRESET, PHASE, TUNE, K - 1>::fast(g, M, ob, x, y, zl, own, e, f);
-        f[K] = aa_gather_fast<PRESET, K, PHASE, TUNE>(g, M, ob, x, y, zl, own, e);
-    }
-    static __device__ __forceinline__ void general(const Geo& g, const float* M, const float* ob,
-                                                   const TileMask& t, int lane, int x, int y, int zl,
-                                                   long long own, float e, float U, float* f) {
-        AaGather<PRESET, PHASE, TUNE, K - 1>::general(g, M, ob, t, lane, x, y, zl, own, e, U, f);
-        f[K] = aa_gather_general<PRESET, K, PHASE>(g, M, ob, t, lane, x, y, zl, own, e, U);
-    }
-    static __device__ __forceinline__ void store(const Geo& g, float* M, long long own, const float* o) {
-        AaGather<PRESET, PHASE, TUNE, K - 1>::store(g, M, own, o);
-        float* dst = PHASE == 0 ? M + (long long)INV[K] * g.plane + own
-                                : M + (long long)K * g.plane + own + dir_off<K>(g);
-        stf<TUNE>(dst, o[K]);
-    }
-};
-template <int PRESET, int PHASE, int TUNE>
-struct AaGather<PRESET, PHASE, TUNE, -1> {
-    static __device__ __forceinline__ void fast(const Geo&, const float*, const float*, int, int, int, long long, float, float*) {}
-    static __device__ __forceinline__ void general(const Geo&, const float*, const float*, const TileMask&, int, int, int, int, long long, float, float, float*) {}
-    static __device__ __forceinline__ void store(const Geo&, float*, long long, const float*) {}
-};
-
-// PHASE 0: even step (reads the streamed layout, writes the swapped one); PHASE 1: odd step.
-template <int PRESET, int PHASE, int TUNE>
-__global__ __launch_bounds__(256) void k_aa_step(
-    float* M, const float* __restrict__ ob_old, float* __restrict__ ob_new,
-    const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
-    float* __restrict__ rho_out, float4* __restrict__ u_out, Geo g, Params p, int segsx_log2, int zrev,
-    int want_moments, int zl_begin, int zl_second) {
-    const TileId t = tile_of_wave(segsx_log2);
-    const int y = t.y;
-    // zl_second > 0: the two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
-    const int zl = zl_second > 0 ? (blockIdx.z == 0 ? zl_begin : zl_second)
-                                 : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
-    if (t.xs >= g.Wt || y >= g.H) return;
-    const int x = t.xs * 64 + t.lane;
-    const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
-    if (x >= g.W) return;
-    if (flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
-    const long long own = cell_off(g, x, y, zl);
-    const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
-    want_moments = want_moments && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
-    const float inlet_e = inlet_bracket(p.U);
-    float f[Q];
-    if (flag == 0) {
-        AaGather<PRESET, PHASE, TUNE, Q - 1>::fast(g, M, ob_old, x, y, zl, own, inlet_e, f);
-    } else {
-        const TileMask tm = load_tile_mask(g, mask, t.xs, y, zl);
-        if ((tm.w[1][1] >> t.lane) & 1ull) {
-            if (want_moments) {
-                rho_out[ridx] = 0.0f;
-                u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            return;
-        }
-        AaGather<PRESET, PHASE, TUNE, Q - 1>::general(g, M, ob_old, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
-    }
-    const Moments m = moments_of(f);
-    if (want_moments) {
-        rho_out[ridx] = m.rho;
-        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
-    }
-    float o[Q];
-    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
-    AaGather<PRESET, PHASE, TUNE, Q - 1>::store(g, M, own, o);
-    if (x == g.W - 1) {
-#pragma unroll
-        for (int i = 0; i < OB_N; i++) ob_new[ob_at(g, i, zl - 1, y)] = o[OB_PLANE[i]];
-    }
-}
-
-__global__ void k_ob_fill(float* __restrict__ a, float* __restrict__ b, long long per_plane) {
-    const long long i = gidx();
-    if (i >= per_plane * OB_N) return;
-    const float w = weight(OB_PLANE[i / per_plane]);
-    a[i] = w;
-    b[i] = w;
-}
-
-// solid cells of the outlet column keep their frozen value in both side buffers
-__global__ void k_ob_sync(const float* __restrict__ cur, float* __restrict__ other,
-                          const unsigned long long* __restrict__ mask, Geo g) {
-    const long long col = gidx();
-    if (col >= (long long)g.D * g.H) return;
-    const int z = (int)(col / g.H), y = (int)(col - (long long)z * g.H);
-    if (!solid_at(g, mask, g.W - 1, y, z + 1)) return;
-    for (int i = 0; i < OB_N; i++) other[ob_at(g, i, z, y)] = cur[ob_at(g, i, z, y)];
-}
-
-// A cell that the new mask turns from solid to fluid restarts from equilibrium (F_k = w_k): the
-// in-place scheme has nowhere to keep a solid cell's frozen populations (documented deviation from
-// the A/B scheme; identical to the reference whenever the cell was solid since init()).
-__global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsigned long long* __restrict__ prev,
-                                const unsigned long long* __restrict__ mask, Geo g, int phase) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    if (!solid_at(g, prev, x, y, z + 1) || solid_at(g, mask, x, y, z + 1)) return;
-    const long long own = cell_off(g, x, y, z + 1);
-    for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
-        if (phase == 0) M[(long long)k * g.plane + own + d] = weight(k);
-        else M[(long long)INV[k] * g.plane + own] = weight(k);
-    }
-    if (x == g.W - 1)
-        for (int j = 0; j < OB_N; j++) ob_cur[ob_at(g, j, z, y)] = weight(OB_PLANE[j]);
-}
-
-// canonical f[k*n + idx] <-> the in-place layout of the moment
-__global__ void k_aa_export(const float* __restrict__ M, float* __restrict__ dense, Geo g, int phase) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    const long long own = cell_off(g, x, y, z + 1);
-    for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
-        dense[(long long)k * n + i] = phase == 0 ? M[(long long)k * g.plane + own + d] : M[(long long)INV[k] * g.plane + own];
-    }
-}
-__global__ void k_aa_import(float* __restrict__ M, float* __restrict__ ob_a, float* __restrict__ ob_b,
-                            const float* __restrict__ dense, Geo g) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    const long long own = cell_off(g, x, y, z + 1);
-    for (int k = 0; k < Q; k++) {
-        const long long d = (long long)CZ[k] * g.layer + (long long)CY[k] * g.row + CX[k];
-        M[(long long)k * g.plane + own + d] = dense[(long long)k * n + i];  // streamed layout
-    }
-    if (x == g.W - 1)
-        for (int j = 0; j < OB_N; j++) {
-            const float v = dense[(long long)OB_PLANE[j] * n + i];
-            ob_a[ob_at(g, j, z, y)] = v;
-            ob_b[ob_at(g, j, z, y)] = v;
-        }
-}
-
-// ------------------------------------------------------------------------------------------
-// set-up and read-back kernels
-// ------------------------------------------------------------------------------------------
-// k_init (lbm_solver.cu:37-64): equilibrium at rho = 1, u = 0 is f_k = w_k exactly.  Fills the
-// whole plane (ghost layers and row padding too) of both buffers.
-// Every float of the allocation [first, last) relative to plane 0 is filled (ghost layers, row
-// padding, skew and the AA front guard too), with the weight of the population whose run it
-// belongs to.
-__global__ void k_fill_planes(float* __restrict__ fa, float* __restrict__ fb, Geo g, int rows_layout,
-                              long long first, long long last) {
-    const long long i = first + gidx();
-    if (i >= last) return;
-    long long k;
-    if (rows_layout) {
-        long long r = i % g.row;
-        if (r < 0) r += g.row;
-        k = r / g.Wp;
-    } else {
-        k = i < 0 ? 0 : i / g.plane;
-    }
-    const float w = weight((int)(k < Q ? k : Q - 1));
-    fa[i] = w;
-    fb[i] = w;
-}
-
-__global__ void k_fill_fields(float* __restrict__ rho, float4* __restrict__ u, long long n) {
-    const long long i = gidx();
-    if (i >= n) return;
-    rho[i] = 1.0f;
-    u[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-}
-
-// dense u8 mask (reference wire format) -> bit-packed words of the owned layers
-__global__ void k_pack_mask(const unsigned char* __restrict__ dense, unsigned long long* __restrict__ mask, Geo g) {
-    const long long wi = gidx();  // word index over owned rows
-    const long long nwords = (long long)g.D * g.H * g.Wm;
-    if (wi >= nwords) return;
-    const long long row = wi / g.Wm;
-    const int xw = (int)(wi - row * g.Wm);
-    const unsigned char* src = dense + row * g.W + (long long)xw * 64;
-    const int cnt = min(64, g.W - xw * 64);
-    unsigned long long bits = 0;
-    for (int b = 0; b < cnt; b++) bits |= (unsigned long long)(src[b] > 0) << b;
-    mask[(long long)g.H * g.Wm + wi] = bits;  // skip the bottom ghost layer
-}
-
-__global__ void k_unpack_mask(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const unsigned long long w = mask[(long long)g.H * g.Wm + row * g.Wm + (x >> 6)];
-    dense[i] = ((w >> (x & 63)) & 1ull) ? 255 : 0;
-}
-
-// k_add_solid_rect (lbm_solver.cu:498-513) on the packed mask: one thread per word, no atomics.
-// Coordinates are global; this context owns global layers [z0, z0+D).
-__global__ void k_add_rect(unsigned long long* __restrict__ mask, Geo g, int rx, int ry, int rz, int rw, int rh, int rd) {
-    const long long wi = gidx();
-    const long long nwords = (long long)(g.D + 2) * g.H * g.Wm;  // ghost layers included
-    if (wi >= nwords) return;
-    const long long row = wi / g.Wm;
-    const int xw = (int)(wi - row * g.Wm);
-    const int zl = (int)(row / g.H);
-    const int y = (int)(row - (long long)zl * g.H);
-    const int zg = zl - 1 + g.z0;
-    if (zg < 0 || zg >= g.Dg) return;
-    // 64-bit compares: rx + rw may exceed int range for hostile arguments
-    if (y < ry || (long long)y >= (long long)ry + rh || zg < rz || (long long)zg >= (long long)rz + rd) return;
-    long long lo = max((long long)rx, (long long)xw * 64);
-    long long hi = min(min((long long)rx + rw, (long long)g.W), (long long)xw * 64 + 64);
-    if (hi <= lo) return;
-    const int b0 = (int)(lo - (long long)xw * 64), cnt = (int)(hi - lo);
-    const unsigned long long bits = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << b0;
-    mask[wi] |= bits;
-}
-
-// ---- device voxeliser (MeshVoxelizer::voxelize, mesh_voxelizer.cpp:146-216, on the GPU) ----------
-// One thread per +X ray (one (y,z) row of the grid), one block per 256 consecutive rows of a z
-// layer.  Triangles stream through LDS in tiles of 256; the z-extent cull is uniform for the
-// block, the y-extent cull and the Moeller-Trumbore test (mesh_voxelizer.cpp:89-121) run per ray
-// in the reference's fp32 operation order (contraction off, IEEE division), so the hit distances
-// -- and with them ceil/floor of the span ends -- equal the host's bit for bit.  Each thread sorts
-// its hits, turns the pairs into bits and writes its row of the packed mask itself (whole words,
-// no atomics); y = 0 becomes the solid floor (lbm_solver.cu:549-553).  A ray with more than
-// VOX_MAX_HITS hits raises `overflow` and the caller falls back to the host voxeliser.
-constexpr int VOX_MAX_HITS = 64;
-constexpr int VOX_TILE = 256;
-struct VoxTri {
-    float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
-    float ymin, ymax, zmin, zmax;
-};
-struct VoxFrame {
-    float gcx, gcy, gcz;  // grid centre (W/2, H/2, D/2)
-    float mcx, mcy, mcz;  // mesh point mapped onto it
-    float scale;
-};
-__device__ __forceinline__ bool vox_hit_plus_x(float ox, float oy, float oz, const VoxTri& t, float& dist) {
-    constexpr float kEps = 0.0000001f;
-    const float e1x = t.v1x - t.v0x, e1y = t.v1y - t.v0y, e1z = t.v1z - t.v0z;
-    const float e2x = t.v2x - t.v0x, e2y = t.v2y - t.v0y, e2z = t.v2z - t.v0z;
-    // h = cross(dir, e2) with dir = (1,0,0), written out as glm::cross evaluates it
-    const float hx = 0.0f * e2z - e2y * 0.0f, hy = 0.0f * e2x - e2z * 1.0f, hz = 1.0f * e2y - e2x * 0.0f;
-    const float a = e1x * hx + e1y * hy + e1z * hz;
-    if (a > -kEps && a < kEps) return false;
-    const float f = 1.0f / a;
-    const float sx = ox - t.v0x, sy = oy - t.v0y, sz = oz - t.v0z;
-    const float u = f * (sx * hx + sy * hy + sz * hz);
-    if (u < 0.0f || u > 1.0f) return false;
-    const float qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;
-    const float v = f * (1.0f * qx + 0.0f * qy + 0.0f * qz);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    dist = f * (e2x * qx + e2y * qy + e2z * qz);
-    return dist > kEps;
-}
-__global__ __launch_bounds__(256) void k_voxelize_rows(const VoxTri* __restrict__ tris, int ntris, VoxFrame fr,
-                                                       unsigned long long* __restrict__ mask, Geo g,
-                                                       int* __restrict__ overflow) {
-    __shared__ VoxTri tile[VOX_TILE];
-    const int z = blockIdx.y;
-    const int y = blockIdx.x * 256 + threadIdx.x;
-    const float ox = (0.0f - fr.gcx) / fr.scale + fr.mcx;
-    const float oy = ((float)y - fr.gcy) / fr.scale + fr.mcy;
-    const float oz = ((float)(z + g.z0) - fr.gcz) / fr.scale + fr.mcz;  // z is this context's layer; the grid is the global domain
-    float hits[VOX_MAX_HITS];
-    int nh = 0;
-    bool over = false;
-    for (int base = 0; base < ntris; base += VOX_TILE) {
-        const int cnt = min(VOX_TILE, ntris - base);
-        __syncthreads();
-        if ((int)threadIdx.x < cnt) tile[threadIdx.x] = tris[base + threadIdx.x];
-        __syncthreads();
-        if (y >= g.H) continue;
-        for (int i = 0; i < cnt; i++) {
-            const VoxTri& t = tile[i];
-            if (oz < t.zmin || oz > t.zmax) continue;  // uniform for the block
-            if (oy < t.ymin || oy > t.ymax) continue;
-            float d;
-            if (vox_hit_plus_x(ox, oy, oz, t, d)) {
-                if (nh < VOX_MAX_HITS) hits[nh++] = d; else over = true;
-            }
-        }
-    }
-    if (y >= g.H) return;
-    if (over) { *overflow = 1; return; }
-    for (int i = 1; i < nh; i++) {  // insertion sort (std::sort on the host: same order of values)
-        const float v = hits[i];
-        int j = i - 1;
-        while (j >= 0 && hits[j] > v) { hits[j + 1] = hits[j]; j--; }
-        hits[j + 1] = v;
-    }
-    unsigned long long* row = mask + ((long long)(z + 1) * g.H + y) * g.Wm;
-    for (int w = 0; w < g.Wm; w++) {
-        const int lo = w * 64;
-        const int valid = min(64, g.W - lo);
-        const unsigned long long all = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
-        unsigned long long bits = 0;
-        if (y == 0) {
-            bits = all;  // floor
-        } else {
-            for (int i = 0; i + 1 < nh; i += 2) {
-                const int x0 = max(0, (int)ceilf(hits[i] * fr.scale));
-                const int x1 = min(g.W, (int)floorf(hits[i + 1] * fr.scale));
-                const int a = max(x0, lo) - lo, b = min(x1, lo + 64) - lo;  // [a, b) inside this word
-                if (b > a) bits |= (b - a >= 64 ? ~0ull : ((1ull << (b - a)) - 1ull)) << a;
-            }
-        }
-        row[w] = bits;
-    }
-}
-
-// per-tile path flag: 0 = interior fast path, 1 = full boundary chain, 2 = every cell solid (skipped)
-template <int PRESET>
-__global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ flags, Geo g) {
-    const long long ti = gidx();
-    const long long ntiles = (long long)g.D * g.H * g.Wt;
-    if (ti >= ntiles) return;
-    const long long row = ti / g.Wt;
-    const int xs = (int)(ti - row * g.Wt);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    const int zg = z + g.z0;
-    unsigned char fl = 0;
-    const int cnt = min(64, g.W - xs * 64);
-    const unsigned long long all = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-    if ((mask[((long long)(z + 1) * g.H + y) * g.Wm + xs] & all) == all) {
-        fl = 2;
-    } else if (y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1) {
-        fl = 1;
-    } else {
-        unsigned long long any = 0;
-        for (int dz = -1; dz <= 1; dz++)
-            for (int dy = -1; dy <= 1; dy++) {
-                const unsigned long long* r = mask + ((long long)(z + 1 + dz) * g.H + (y + dy)) * g.Wm;
-                any |= r[xs];
-                if (xs > 0) any |= r[xs - 1] >> 63;
-                if (xs + 1 < g.Wm) any |= r[xs + 1] & 1ull;
-            }
-        fl = any != 0;
-    }
-    flags[ti] = fl;
-}
-
-// Solid cells keep their populations frozen; the reference re-copies them every step
-// (lbm_solver.cu:263-265), which only matters because the outlet branch may read a solid cell.
-// One copy cur -> other after the mask (or the populations) changed gives the same state.
-__global__ void k_sync_solid(const float* __restrict__ cur, float* __restrict__ other,
-                             const unsigned long long* __restrict__ mask, Geo g) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    if (!solid_at(g, mask, x, y, z + 1)) return;
-    const long long off = cell_off(g, x, y, z + 1);
-    for (int k = 0; k < Q; k++) other[(long long)k * g.plane + off] = cur[(long long)k * g.plane + off];
-}
-
-template <int PRESET>
-__global__ void k_classify(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ cls, Geo g) {
-    const long long i = gidx();
-    const long long n = (long long)g.W * g.H * g.D;
-    if (i >= n) return;
-    const long long row = i / g.W;
-    const int x = (int)(i - row * g.W);
-    const int z = (int)(row / g.H);
-    const int y = (int)(row - (long long)z * g.H);
-    unsigned char out[Q];
-    if (solid_at(g, mask, x, y, z + 1)) {
-        for (int k = 0; k < Q; k++) out[k] = SRC_PULL;
-    } else {
-        GatherAll<PRESET, Q - 1>::classify(g, mask, x, y, z + 1, out);
-    }
-    for (int k = 0; k < Q; k++) cls[i * Q + k] = out[k];
-}
-
-// ---- z-slab halo messages -------------------------------------------------------------------
-// message = 5 population layers (layer floats each) followed by `tail` floats of outlet-edge values:
-//   top message   (side 1, from layer zl = D): planes 5,11,14,15,18; tail = f10(W-1,H-1), f9(W-1,H-1), f13(W-1,y) for all y
-//   bottom message(side 0, from layer zl = 1): planes 6,12,13,16,17; tail = f8(W-1,0),  f9(W-1,0)
-// The tails are what the unchecked outlet index of the reference (lbm_solver.cu:292-296) reads
-// across a z face; they land in ghost-layer planes that the regular exchange does not use.
-__device__ __forceinline__ int halo_plane(int side, int j) { return side ? UP5[j] : DOWN5[j]; }
-
-__global__ void k_halo_pack(const float* __restrict__ f, float* __restrict__ msg, Geo g, int side) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int zl = side ? g.D : 1;
-    if (j < 5) {
-        if (i < g.mlayer) msg[(long long)j * g.mlayer + i] = f[(long long)halo_plane(side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)];
-        return;
-    }
-    float* tail = msg + 5 * g.mlayer;
-    if (i >= g.H + 2) return;
-    float v = 0.0f;
-    if (side) {
-        if (i == 0) v = f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)];
-        else if (i == 1) v = f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)];
-        else v = f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)];
-    } else {
-        if (i == 0) v = f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)];
-        else if (i == 1) v = f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)];
-    }
-    tail[i] = v;
-}
-
-// side 0: message from the lower neighbour's TOP face -> bottom ghost layer (zl = 0)
-// side 1: message from the upper neighbour's BOTTOM face -> top ghost layer (zl = D+1)
-__global__ void k_halo_unpack(float* __restrict__ f, const float* __restrict__ msg, Geo g, int side) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    const int zl = side ? g.D + 1 : 0;
-    if (j < 5) {
-        // the message that arrives on our bottom face is the sender's top message (planes UP5)
-        if (i < g.mlayer) f[(long long)halo_plane(1 - side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)] = msg[(long long)j * g.mlayer + i];
-        return;
-    }
-    const float* tail = msg + 5 * g.mlayer;
-    if (side == 0) {
-        if (i >= g.H + 2) return;
-        if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
-        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[1];
-        else f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)] = tail[i];
-    } else {
-        if (i == 0) f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[0];
-        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[1];
-    }
-}
-
-__global__ void k_halo_unpack2(float* __restrict__ f, const float* __restrict__ from_below,
-                               const float* __restrict__ from_above, Geo g) {
-    const int side = blockIdx.y / 6;
-    const float* msg = side ? from_above : from_below;
-    if (!msg) return;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y % 6;
-    const int zl = side ? g.D + 1 : 0;
-    if (j < 5) {
-        if (i < g.mlayer) f[(long long)halo_plane(1 - side, j) * g.plane + cell_off(g, (int)(i % g.Wp), (int)(i / g.Wp), zl)] = msg[(long long)j * g.mlayer + i];
-        return;
-    }
-    const float* tail = msg + 5 * g.mlayer;
-    if (side == 0) {
-        if (i >= g.H + 2) return;
-        if (i == 0) f[10 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[0];
-        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, g.H - 1, zl)] = tail[1];
-        else f[13 * g.plane + cell_off(g, g.W - 1, (int)i - 2, zl)] = tail[i];
-    } else {
-        if (i == 0) f[8 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[0];
-        else if (i == 1) f[9 * g.plane + cell_off(g, g.W - 1, 0, zl)] = tail[1];
-    }
-}
-
-// ---- AA z-slab halo ---------------------------------------------------------------------------
-// Which slots carry the five populations that cross a face depends on the layout of the moment:
-//   swapped  (after an EVEN step): F_k of a boundary-layer cell sits in the OWNED layer at plane
-//            inv(k); it goes to the same plane of the neighbour's GHOST layer, where the
-//            neighbour's odd step pulls it from;
-//   streamed (after an ODD step, or after init / import): the cell has pushed F_k into OUR GHOST
-//            layer at plane k; it goes to the neighbour's OWNED boundary layer, same plane, where
-//            the neighbour's even step reads its own slots.
-// Only cells x < W, 0 <= y < H travel: the x/y ghost shell of a layer belongs to the wall logic of
-// the slab that wrote it.  Message = 5 layers of H*Wp floats + the 7 outlet-column planes of the
-// boundary layer (7*H floats, what aa_outlet_read needs across the face, ring link included).
-__global__ void k_aa_halo_pack(const float* __restrict__ M, const float* __restrict__ ob, float* __restrict__ msg,
-                               Geo g, int side, int streamed) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (j < 5) {
-        if (i >= g.mlayer) return;
-        const int x = (int)(i % g.Wp), y = (int)(i / g.Wp);
-        if (x >= g.W) return;
-        const int zl = streamed ? (side ? g.D + 1 : 0) : (side ? g.D : 1);
-        const int pl = streamed ? (side ? UP5[j] : DOWN5[j]) : (side ? DOWN5[j] : UP5[j]);
-        msg[(long long)j * g.mlayer + i] = M[(long long)pl * g.plane + cell_off(g, x, y, zl)];
-        return;
-    }
-    if (i >= (long long)OB_N * g.H) return;
-    msg[5 * g.mlayer + i] = ob[ob_at(g, (int)(i / g.H), side ? g.D - 1 : 0, (int)(i % g.H))];
-}
-// side: the face of THIS slab the message arrived on (0: from the lower neighbour's top face)
-__global__ void k_aa_halo_unpack(float* __restrict__ M, float* __restrict__ ob, const float* __restrict__ msg,
-                                 Geo g, int side, int streamed) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (j < 5) {
-        if (i >= g.mlayer) return;
-        // the ring link of the wind-tunnel preset carries only the outlet column: beyond a domain end
-        // there is no cell, and the ghost slots there belong to this slab's own wall logic
-        if (side ? (g.z0 + g.D == g.Dg) : (g.z0 == 0)) return;
-        const int x = (int)(i % g.Wp), y = (int)(i / g.Wp);
-        if (x >= g.W) return;
-        const int zl = streamed ? (side ? g.D : 1) : (side ? g.D + 1 : 0);
-        const int pl = streamed ? (side ? DOWN5[j] : UP5[j]) : (side ? UP5[j] : DOWN5[j]);
-        M[(long long)pl * g.plane + cell_off(g, x, y, zl)] = msg[(long long)j * g.mlayer + i];
-        return;
-    }
-    if (i >= (long long)OB_N * g.H) return;
-    ob[ob_at(g, (int)(i / g.H), side ? g.D : -1, (int)(i % g.H))] = msg[5 * g.mlayer + i];
-}
-
-// one layer of the packed mask <-> dense u8 (ghost exchange of the static mask)
-__global__ void k_mask_layer_get(const unsigned long long* __restrict__ mask, unsigned char* __restrict__ dense, Geo g, int zl) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)g.W * g.H) return;
-    const int y = (int)(i / g.W), x = (int)(i - (long long)y * g.W);
-    dense[i] = solid_at(g, mask, x, y, zl) ? 255 : 0;
-}
-__global__ void k_mask_layer_set(unsigned long long* __restrict__ mask, const unsigned char* __restrict__ dense, Geo g, int zl) {
-    const long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= (long long)g.H * g.Wm) return;
-    const int y = (int)(wi / g.Wm), xw = (int)(wi - (long long)y * g.Wm);
-    const unsigned char* src = dense + (long long)y * g.W + (long long)xw * 64;
-    const int cnt = min(64, g.W - xw * 64);
-    unsigned long long bits = 0;
-    for (int b = 0; b < cnt; b++) bits |= (unsigned long long)(src[b] > 0) << b;
-    mask[(long long)zl * g.H * g.Wm + wi] = bits;
-}
-
-// k_compute_curl (lbm_solver.cu:612-656): |curl u| by clamped central differences.
-__global__ void k_curl(const float4* __restrict__ u, float* __restrict__ curl, int W, int H, int D) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int z = blockIdx.z;
-    if (x >= W) return;
-    auto at = [&](int ix, int iy, int iz) -> float4 {
-        ix = max(0, min(ix, W - 1));
-        iy = max(0, min(iy, H - 1));
-        iz = max(0, min(iz, D - 1));
-        return u[((long long)iz * H + iy) * W + ix];
-    };
-    const float4 xp = at(x + 1, y, z), xm = at(x - 1, y, z);
-    const float4 yp = at(x, y + 1, z), ym = at(x, y - 1, z);
-    const float4 zp = at(x, y, z + 1), zm = at(x, y, z - 1);
-    const float dv_dx = (xp.y - xm.y) * 0.5f;
-    const float dw_dx = (xp.z - xm.z) * 0.5f;
-    const float du_dy = (yp.x - ym.x) * 0.5f;
-    const float dw_dy = (yp.z - ym.z) * 0.5f;
-    const float du_dz = (zp.x - zm.x) * 0.5f;
-    const float dv_dz = (zp.y - zm.y) * 0.5f;
-    const float cxv = dw_dy - dv_dz;
-    const float cyv = du_dz - dw_dx;
-    const float czv = dv_dx - du_dy;
-    curl[((long long)z * H + y) * W + x] = sqrtf(cxv * cxv + cyv * cyv + czv * czv);
-}
-
-// Derived fields for the visualisation consumers either side of the path (the reference's renderer
-// samples u as an RGBA32F volume: renderer.cpp:1382-1389, raymarch.frag / streamline.comp).
-// strided sample of u: out[(k*ny + j)*nx + i] = u(i*sx, j*sy, k*sz); speed = |u.xyz|
-__global__ void k_sample_velocity(const float4* __restrict__ u, float4* __restrict__ out, int W, int H,
-                                  int nx, int ny, int nz, int sx, int sy, int sz) {
-    const long long i = gidx();
-    if (i >= (long long)nx * ny * nz) return;
-    const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((long long)nx * ny));
-    out[i] = u[((long long)iz * sz * H + (long long)iy * sy) * W + (long long)ix * sx];
-}
-__global__ void k_speed(const float4* __restrict__ u, float* __restrict__ out, long long n) {
-    const long long i = gidx();
-    if (i >= n) return;
-    const float4 v = u[i];
-    out[i] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);  // cuda_math::length, cuda_math.cuh:142-145
-}
+#include "k_step.h"
+#include "k_aa.h"
+#include "k_setup.h"
+#include "k_voxelize.h"
+#include "k_mask.h"
+#include "k_halo.h"
+#include "k_fields.h"
 
 }  // namespace
 
