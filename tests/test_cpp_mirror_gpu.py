@@ -28,3 +28,16 @@ def test_headless_driver_known_answer(tmp_path):
     assert "solid=9196" in r.stdout and "sum_rho=255103.576208234" in r.stdout, r.stdout
     assert os.path.getsize(prefix + ".u.raw") == 64 ** 3 * 16
     assert os.path.getsize(prefix + ".solid.raw") == 64 ** 3
+
+
+@pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--preset", "cavity"], ["--autotune", "--steps", "120"]])
+def test_native_rccl_slab_driver(extra):
+    """tools/lbm_slab_rccl.cpp: C++ host, RCCL ncclSend/ncclRecv between the slabs of one process.
+    On this one-GPU box the wind-tunnel ring sends to itself through RCCL; --check compares with the
+    undecomposed run bit for bit."""
+    exe = os.path.join(CSRC, "lbm_slab_rccl")
+    assert os.path.exists(exe), "build it with make -C cfd_amd/csrc"
+    r = subprocess.run([exe, "--dims", "96", "48", "40", "--gpus", "1", "--steps", "25", "--obj", CUBE_OBJ, "--check"] + extra,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit-identical" in r.stdout, r.stdout
