@@ -84,19 +84,21 @@ __device__ __forceinline__ float aa_gather_fast(const Geo& g, const float* M, co
     constexpr int cx = CX[K];
     const float* p = aa_pull_pop<K, PHASE>(g, M, own);
     if (cx == 0) return ldf<TUNE>(p);
+    // one load per direction, the special lane by an address select (no divergent branch); in the
+    // odd phase the x-shifted loads are misaligned and keep the default cache policy like the A/B
+    // fast path (ldk), in the even phase every load is an aligned own-cell slot
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
         if (cx == 1) {
-            const float v = ldf<TUNE>(p);  // x = 0 reads a ghost slot: in bounds, discarded
+            const float v = PHASE ? ldk<TUNE, K>(p) : ldf<TUNE>(p);  // x = 0 reads a ghost slot: in bounds, discarded
             return x == 0 ? weight(K) * inlet_e : v;
         }
-        if (x == g.W - 1)  // interior tile: ny, nz are in range
-            return ob_old[ob_at(g, ob_index(K), zl - 1 - CZ[K], y - CY[K])];
-        return ldf<TUNE>(p);
+        // interior tile: ny, nz are in range
+        if (x == g.W - 1) p = ob_old + ob_at(g, ob_index(K), zl - 1 - CZ[K], y - CY[K]);
     } else {
         const bool wall = (cx == 1) ? (x == 0) : (x == g.W - 1);
-        if (wall) return *aa_own_pop<INV[K], PHASE>(g, M, own);
-        return ldf<TUNE>(p);
+        if (wall) p = aa_own_pop<INV[K], PHASE>(g, M, own);
     }
+    return PHASE ? ldk<TUNE, K>(p) : ldf<TUNE>(p);
 }
 
 template <int PRESET, int PHASE, int TUNE, int K>
