@@ -118,7 +118,10 @@ struct AaGather {
         AaGather<PRESET, PHASE, TUNE, K - 1>::store(g, M, own, o);
         float* dst = PHASE == 0 ? M + (long long)INV[K] * g.plane + own
                                 : M + (long long)K * g.plane + own + dir_off<K>(g);
-        stf<TUNE>(dst, o[K]);
+        // odd phase, x-shifted rows: two waves share the first / last 128-byte line of a segment;
+        // write-back stores let L2 merge the halves, nt stores would send partial lines to HBM
+        if (PHASE == 1 && CX[K] != 0) *dst = o[K];
+        else stf<TUNE>(dst, o[K]);
     }
 };
 template <int PRESET, int PHASE, int TUNE>
