@@ -84,7 +84,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="index into BASELINE.json configs")
     ap.add_argument("--size", type=int, nargs=3, default=None, help="per-GPU W H D (overrides the config's size)")
     ap.add_argument("--preset", choices=["cavity", "wind_tunnel"], default=None)
-    ap.add_argument("--scheme", choices=["ab", "aa"], default=None)
+    ap.add_argument("--scheme", choices=["ab", "aa", "slide"], default=None)
+    ap.add_argument("--slide-chunk", type=int, default=0, help="--scheme slide: layers per launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-slab", action="store_true",
                     help="N = 1 only: run the z-slab code path of N > 1 (split step, RCCL ring to itself)")
@@ -121,11 +122,14 @@ def main():
     else:
         Dg = D * world
     preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
-    scheme = lbm.SCHEME_AA if scheme_name == "aa" else lbm.SCHEME_AB
+    scheme = {"ab": lbm.SCHEME_AB, "aa": lbm.SCHEME_AA, "slide": lbm.SCHEME_SLIDE}[scheme_name]
+    scheme_text = {"ab": "A/B pull", "aa": "AA in-place", "slide": "sliding in-place A/B"}[scheme_name]
     car = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
     dist = None
     if world > 1 or args.rehearse_slab:
+        if scheme == lbm.SCHEME_SLIDE:
+            raise SystemExit("--scheme slide does not run as z-slabs (use ab or aa)")
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -150,7 +154,7 @@ def main():
         drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
         step = drv.step
     else:
-        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, scheme=scheme)
+        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, scheme=scheme, slide_chunk=args.slide_chunk)
         if args.config == 4:
             solver.set_field_window(0, 4)   # sized to HBM: no room for whole-domain rho/u (20 B/cell)
         solver.init()
@@ -208,7 +212,7 @@ def main():
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, "
-                                   f"{'AA in-place' if scheme == lbm.SCHEME_AA else 'A/B pull'}, "
+                                   f"{scheme_text}, "
                                    f"{'voxelised car stand-in, ' if obstacle else ''}"
                                    f"{'z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo' if world > 1 else 'one GPU'}"
                                    f" (BASELINE.json configs[{args.config}])",
@@ -218,7 +222,7 @@ def main():
             "mlups_per_gpu": round(mlups_total / world, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "k_stream_collide",
+                         "traffic": traffic, "kernel": "k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide",
                          "launch_ms": round(dev_ms_per_step, 5),
                          "algorithmic_bytes_per_launch": fluid * BYTES_PER_CELL,
                          "fluid_cells_per_launch": fluid},

@@ -20,13 +20,6 @@
 // linearly (x = -1 is the last pad slot of the previous row, y = -1 the last row of the previous
 // layer), which keeps x = 0 on a 128-byte boundary.
 // ------------------------------------------------------------------------------------------
-constexpr int OB_N = 7;
-constexpr int OB_PLANE[OB_N] = {2, 8, 9, 10, 12, 13, 14};
-__host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <= 10 ? pl - 7 : pl - 8); }
-// side-array slot of plane-slot i, local layer z in [-1, D] (ghost rows for the z-slab halo), row y
-__device__ __forceinline__ long long ob_at(const Geo& g, int i, int z, int y) {
-    return ((long long)i * (g.D + 2) + (z + 1)) * g.H + y;
-}
 
 template <int K>
 __device__ __forceinline__ long long dir_off(const Geo& g) {
@@ -46,20 +39,6 @@ __device__ __forceinline__ const float* aa_pull_pop(const Geo& g, const float* M
                       : M + (long long)INV[K] * g.plane + own - dir_off<K>(g);
 }
 
-template <int K>
-__device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __restrict__ ob_old, int y, int zl) {
-    int pl = K;
-    int ny = y - CY[K];
-    int nz = (zl - 1) - CZ[K];
-    if (ny < 0) { ny += g.H; nz -= 1; }
-    else if (ny >= g.H) { ny -= g.H; nz += 1; }
-    // as outlet_off(): an undecomposed domain wraps to its own far layer, a slab finds the
-    // neighbour's (or, over the ring link, the far rank's) column in its ghost row
-    const int nzg = nz + g.z0;
-    if (nzg < 0) { pl -= 1; if (!g.slab) nz += g.D; }
-    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nz -= g.D; }
-    return ob_old[ob_at(g, ob_index(pl), nz, ny)];
-}
 
 template <int PRESET, int K, int PHASE>
 __device__ __forceinline__ float aa_gather_general(const Geo& g, const float* M, const float* __restrict__ ob_old,
@@ -219,6 +198,19 @@ __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsi
     }
     if (x == g.W - 1)
         for (int j = 0; j < OB_N; j++) ob_cur[ob_at(g, j, z, y)] = weight(OB_PLANE[j]);
+}
+
+// outlet column of plainly addressed populations -> both side arrays (after lbm_write_populations)
+__global__ void k_ob_gather(const float* __restrict__ f, float* __restrict__ ob_a, float* __restrict__ ob_b, Geo g) {
+    const long long col = gidx();
+    if (col >= (long long)g.D * g.H) return;
+    const int z = (int)(col / g.H), y = (int)(col - (long long)z * g.H);
+    const long long own = cell_off(g, g.W - 1, y, z + 1);
+    for (int j = 0; j < OB_N; j++) {
+        const float v = f[(long long)OB_PLANE[j] * g.plane + own];
+        ob_a[ob_at(g, j, z, y)] = v;
+        ob_b[ob_at(g, j, z, y)] = v;
+    }
 }
 
 // canonical f[k*n + idx] <-> the in-place layout of the moment

@@ -161,22 +161,57 @@ __device__ __forceinline__ float outlet_read(const Geo& g, const float* __restri
     return fin[outlet_off<K>(g, y, zl)];
 }
 
+// Outlet column side array `ob` (in-place schemes).  The outlet branch copies from another FLUID cell
+// of the x = W-1 column (and, through quirk Q2, from the far end of the domain), which an in-place
+// update would race with or have overwritten already: the seven planes it can touch are mirrored
+// for that column in a small double-buffered array that x = W-1 cells write each step and read the
+// step after.
+constexpr int OB_N = 7;
+constexpr int OB_PLANE[OB_N] = {2, 8, 9, 10, 12, 13, 14};
+__host__ __device__ constexpr int ob_index(int pl) { return pl == 2 ? 0 : (pl <= 10 ? pl - 7 : pl - 8); }
+// side-array slot of plane-slot i, local layer z in [-1, D] (ghost rows for the z-slab halo), row y
+__device__ __forceinline__ long long ob_at(const Geo& g, int i, int z, int y) {
+    return ((long long)i * (g.D + 2) + (z + 1)) * g.H + y;
+}
+
+// the in-place form of outlet_read(): same carry rules, value taken from the side array
+template <int K>
+__device__ __forceinline__ float aa_outlet_read(const Geo& g, const float* __restrict__ ob_old, int y, int zl) {
+    int pl = K;
+    int ny = y - CY[K];
+    int nz = (zl - 1) - CZ[K];
+    if (ny < 0) { ny += g.H; nz -= 1; }
+    else if (ny >= g.H) { ny -= g.H; nz += 1; }
+    // as outlet_off(): an undecomposed domain wraps to its own far layer, a slab finds the
+    // neighbour's (or, over the ring link, the far rank's) column in its ghost row
+    const int nzg = nz + g.z0;
+    if (nzg < 0) { pl -= 1; if (!g.slab) nz += g.D; }
+    else if (nzg >= g.Dg) { pl += 1; if (!g.slab) nz -= g.D; }
+    return ob_old[ob_at(g, ob_index(pl), nz, ny)];
+}
+
 // full boundary chain for one direction, per lane: the branch is turned into an address by
 // selects, so every lane issues exactly one load and no load waits for another
-template <int PRESET, int K>
+template <int PRESET, int K, int OB>
 __device__ __forceinline__ float gather_general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
-                                                int lane, int x, int y, int zl, long long own, float inlet_e, float U) {
+                                                int lane, int x, int y, int zl, long long own, float inlet_e, float U,
+                                                const float* __restrict__ ob_old) {
     const unsigned code = classify_with<PRESET, K>(g, x, y, zl, [&] { return tile_nb_solid<K>(t, lane); });
     // own-cell sources: ceiling / side mirror, bounce-back (floor, solid, wall, lid); an inlet lane
     // loads its own slot and discards it
     const int pl = code == SRC_CEIL_RFY ? RFY[K] : (code == SRC_SIDE_RFZ ? RFZ[K] : (code == SRC_INLET ? K : INV[K]));
     long long a = (long long)pl * g.plane + own;
     if (code == SRC_PULL) a = (long long)K * g.plane + own - ((long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K]);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) {
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && !OB) {
         const long long ao = outlet_off<K>(g, y, zl);  // wave-uniform
         if (code == SRC_OUTLET) a = ao;
     }
     float v = fin[a];
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && OB) {
+        // sliding in-place scheme: the column's values of the previous step come from the side array
+        // (an outlet lane loaded its own slot above and discards it)
+        if (code == SRC_OUTLET) v = aa_outlet_read<K>(g, ob_old, y, zl);
+    }
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == 1 && code == SRC_INLET) v = weight(K) * inlet_e;
     if (PRESET == LBM_PRESET_CAVITY && code == SRC_LID_BB) v = v + lid_term(K, U);
     return v;
@@ -213,11 +248,12 @@ struct GatherAll {
         GatherAll<PRESET, K - 1>::template fast<TUNE>(g, fin, x, y, zl, own, inlet_e, f);
         f[K] = gather_fast<PRESET, K, TUNE>(g, fin, x, y, zl, own, inlet_e);
     }
+    template <int OB>
     static __device__ __forceinline__ void general(const Geo& g, const float* __restrict__ fin, const TileMask& t,
                                                    int lane, int x, int y, int zl, long long own, float inlet_e,
-                                                   float U, float* f) {
-        GatherAll<PRESET, K - 1>::general(g, fin, t, lane, x, y, zl, own, inlet_e, U, f);
-        f[K] = gather_general<PRESET, K>(g, fin, t, lane, x, y, zl, own, inlet_e, U);
+                                                   float U, const float* __restrict__ ob_old, float* f) {
+        GatherAll<PRESET, K - 1>::template general<OB>(g, fin, t, lane, x, y, zl, own, inlet_e, U, ob_old, f);
+        f[K] = gather_general<PRESET, K, OB>(g, fin, t, lane, x, y, zl, own, inlet_e, U, ob_old);
     }
     static __device__ __forceinline__ void classify(const Geo& g, const unsigned long long* __restrict__ mask,
                                                     int x, int y, int zl, unsigned char* out) {
@@ -229,8 +265,9 @@ template <int PRESET>
 struct GatherAll<PRESET, -1> {
     template <int TUNE>
     static __device__ __forceinline__ void fast(const Geo&, const float*, int, int, int, long long, float, float*) {}
+    template <int OB>
     static __device__ __forceinline__ void general(const Geo&, const float*, const TileMask&, int, int, int, int,
-                                                   long long, float, float, float*) {}
+                                                   long long, float, float, const float*, float*) {}
     static __device__ __forceinline__ void classify(const Geo&, const unsigned long long*, int, int, int,
                                                     unsigned char*) {}
 };
@@ -255,6 +292,10 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
 // MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
 // MODE 2: step of the one or two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
 //         that also writes the outgoing halo messages, so no separate pack pass is needed.
+// MODE 3: step of the sliding in-place scheme (LBM_SCHEME_SLIDE): fin and fout are the SAME buffer
+//         at different layer offsets, launched chunk by chunk (see slide_step() on the host); the
+//         outlet branch reads the side array, x = W-1 cells write it, and rho/u are written here
+//         when asked for (there is no intact previous buffer to recompute them from).
 // ------------------------------------------------------------------------------------------
 // message layout: see k_halo_pack
 __device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
@@ -279,7 +320,8 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
     float* __restrict__ rho_out, float4* __restrict__ u_out,
     Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
-    int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top) {
+    int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top,
+    const float* __restrict__ ob_old, float* __restrict__ ob_new, int want_moments) {
     const TileId t = tile_of_wave(segsx_log2);
     const int y = t.y;
     // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
@@ -291,6 +333,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
     if (x >= g.W) return;
     if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
+    if (MODE == 3) want_moments = want_moments && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
 
     const long long own = cell_off(g, x, y, zl);
     const float inlet_e = inlet_bracket(p.U);
@@ -303,27 +346,34 @@ __global__ __launch_bounds__(256) void k_stream_collide(
         if ((tm.w[1][1] >> t.lane) & 1ull) {
             // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
             // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
-            if (MODE == 1) {
+            if (MODE == 1 || (MODE == 3 && want_moments)) {
                 const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
                 rho_out[ridx] = 0.0f;
                 u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
+            if (MODE == 2 || MODE == 3) {
+#pragma unroll
                 for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
+            }
+            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
                 if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
                 if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
             }
+            if (MODE == 3) {  // the lattice moves: a solid cell's frozen populations move with it
+#pragma unroll
+                for (int k = 0; k < Q; k++) fout[(long long)k * g.plane + own] = f[k];
+            }
             return;
         }
-        GatherAll<PRESET, Q - 1>::general(g, fin, tm, t.lane, x, y, zl, own, inlet_e, p.U, f);
+        GatherAll<PRESET, Q - 1>::template general<(MODE == 3)>(g, fin, tm, t.lane, x, y, zl, own, inlet_e, p.U, ob_old, f);
     }
 
     const Moments m = moments_of(f);
-    if (MODE == 1) {
+    if (MODE == 1 || (MODE == 3 && want_moments)) {
         const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
         rho_out[ridx] = m.rho;
         u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
-        return;
+        if (MODE == 1) return;
     }
     float o[Q];
     collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
@@ -333,5 +383,9 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     if (MODE == 2) {
         if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, o);
         if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, o);
+    }
+    if (MODE == 3 && x == g.W - 1) {
+#pragma unroll
+        for (int i = 0; i < OB_N; i++) ob_new[ob_at(g, i, zl - 1, y)] = o[OB_PLANE[i]];
     }
 }

@@ -76,6 +76,13 @@ struct lbm_ctx {
     int zrev = 0;
     int scheme = LBM_SCHEME_AB;
     int aa_phase = 0;          // AA: 0 = next step is even (buffer in the streamed layout)
+    int slide_chunk = 0;     // SLIDE: layers per launch; the lattice moves by slide_chunk + 2 layers per step
+    bool f1_in_alloc0 = false;
+    bool probe = false;        // LBM_PROBE=1: launch knobs are re-read from the environment at every lbm_step (tuning probes)
+    int ab_chunk = 0;        // A/B: layers per launch (0 = the whole domain in one launch)
+    long long slide_off = 0;   // SLIDE: offset (floats) of the lattice inside the buffer right now: 0 or slide_shift
+    long long slide_shift = 0; // SLIDE: (chunk + 2) layers + slide_skew
+    long long slide_skew = 0;  // SLIDE: extra floats between the two positions (DRAM bank alignment of loads against stores)
     float* alloc0 = nullptr;   // AA: start of the allocation (f[0] sits behind a front guard)
     float* ob[2] = {nullptr, nullptr};
     int ob_cur = 0;
@@ -130,6 +137,11 @@ static inline dim3 grid1(long long n, int bs = 256) {
     return dim3((unsigned)gx, (unsigned)((blocks + gx - 1) / gx));
 }
 
+// the populations of the current time level (the sliding scheme keeps them at a layer offset)
+static inline float* current_populations(lbm_ctx* c) {
+    return c->scheme == LBM_SCHEME_SLIDE ? c->f[0] + c->slide_off : c->f[c->cur];
+}
+
 static int ensure_field_buffers(lbm_ctx* c) {
     const long long n = field_cells(c);
     if (n == 0) return LBM_OK;
@@ -155,6 +167,12 @@ static int refresh_mask_state(lbm_ctx* c) {
                            c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->prev_mask, c->mask, c->mask_bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->scheme == LBM_SCHEME_SLIDE) {
+        // solid cells are carried along by the step itself (k_stream_collide MODE 3); only the outlet
+        // column's side array needs the frozen values in both of its buffers
+        hipLaunchKernelGGL(k_ob_sync, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
+                           c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
+        HIPCHK(c, hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream,
                            c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
@@ -166,7 +184,8 @@ static int refresh_mask_state(lbm_ctx* c) {
 
 template <int MODE>
 static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers,
-                                 int zl_second = 0, float* msg_bottom = nullptr, float* msg_top = nullptr) {
+                                 int zl_second = 0, float* msg_bottom = nullptr, float* msg_top = nullptr,
+                                 int want_moments = 0) {
     if (nlayers <= 0) return LBM_OK;
     hipStream_t stream = (MODE == 2 && c->stream_b) ? c->stream_b : c->stream;
     const int segsx = 1 << c->segsx_log2;
@@ -174,7 +193,8 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     const int zrev = (MODE == 0 && (c->tune & 4)) ? c->zrev : 0;
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
     hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
-                       c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top)
+                       c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top,     \
+                       c->ob[c->ob_cur], c->ob[1 - c->ob_cur], want_moments)
 #define LBM_LAUNCH_T(PRESET)                          \
     switch (c->tune & 3) {                            \
         case 0: LBM_LAUNCH(PRESET, 0); break;         \
@@ -230,6 +250,32 @@ static int launch_aa_step(lbm_ctx* c, int want_moments) {
     return rc;
 }
 
+// Sliding in-place scheme: ONE buffer holds the lattice at a layer offset that alternates between 0
+// and S = chunk + 2.  A step reads the lattice at one offset and writes it at the other, chunk by
+// chunk in the direction of the shift (lattice at 0 -> written at S: top chunk first; at S ->
+// written at 0: bottom chunk first).  A chunk of K <= S-2 layers writes absolute layers that lie
+// outside everything it reads ([zb+S, zb+K-1+S] against [zb-1, zb+K]), and the input layers it
+// overwrites are only needed by chunks that have already run; launches on one stream serialise.
+// So the update has the access pattern of the A/B kernel (aligned stores, pulled loads) with
+// 1 + S/D of one buffer instead of two.  The outlet branch, which would read layers the sweep has
+// overwritten (quirk Q2 wraps to the far end), goes through the `ob` side array as in AA.
+static int slide_step(lbm_ctx* c, int want_moments) {
+    const int K = c->slide_chunk, D = c->g.D;
+    const bool up = c->slide_off == 0;
+    const float* fin = c->f[0] + c->slide_off;
+    float* fout = c->f[0] + (up ? c->slide_shift : 0);
+    const int nchunks = (D + K - 1) / K;
+    for (int i = 0; i < nchunks; i++) {
+        const int j = up ? nchunks - 1 - i : i;
+        const int nl = D - j * K < K ? D - j * K : K;
+        int rc = launch_stream_collide<3>(c, fin, fout, c->p, 1 + j * K, nl, 0, nullptr, nullptr, want_moments);
+        if (rc) return rc;
+    }
+    c->slide_off = up ? c->slide_shift : 0;
+    c->ob_cur ^= 1;
+    return LBM_OK;
+}
+
 // bring rho/u up to date: what the reference's per-step writes would hold right now
 static int materialise_fields(lbm_ctx* c) {
     if (c->g.fnz == 0) return fail(c, LBM_ERR_STATE, "the field window is empty (lbm_set_field_window)");
@@ -239,8 +285,8 @@ static int materialise_fields(lbm_ctx* c) {
     if (c->fields == FIELDS_INIT) {
         hipLaunchKernelGGL(k_fill_fields, grid1(field_cells(c)), dim3(256), 0, c->stream, c->rho, c->u, field_cells(c));
         HIPCHK(c, hipGetLastError());
-    } else if (c->scheme == LBM_SCHEME_AA) {
-        return fail(c, LBM_ERR_STATE, "AA scheme: rho/u of a new field window exist after the next lbm_step()");
+    } else if (c->scheme != LBM_SCHEME_AB) {
+        return fail(c, LBM_ERR_STATE, "in-place schemes: rho/u of a new field window exist after the next lbm_step()");
     } else {
         // the last step read f[1-cur]; it is still intact (A/B), so the same gather gives the
         // same post-stream moments (lbm_solver.cu:320-337)
@@ -250,6 +296,21 @@ static int materialise_fields(lbm_ctx* c) {
     c->fields = FIELDS_VALID;
     c->curl_valid = false;
     return LBM_OK;
+}
+
+// Layers per launch.  Measured on MI355X (profiles/r01_tuning.md, "layers per launch"): a step cut into
+// launches of about 1 GB of algorithmic traffic runs 2-4 % faster than one launch over the whole
+// domain (256^3: 6.09 -> 6.27 TB/s at 96 layers, 512x256x256: 5.75 -> 5.98 at 32-64, 1024x512x512:
+// 5.96 -> 6.08 at 16-32), as long as a launch keeps >= 48 K workgroups or so in flight
+// (2048x1024x128 loses 1-2 % below 8 layers).  Chunks are balanced over the depth.
+static int auto_chunk(const Geo& g, int segsx_log2) {
+    const int segsx = 1 << segsx_log2;
+    const long long bpl = (long long)((g.Wt + segsx - 1) / segsx) * ((g.H + (4 / segsx) - 1) / (4 / segsx));  // workgroups per layer
+    const long long layer_bytes = (long long)g.W * g.H * 152;
+    long long k = std::max(((1ll << 30) + layer_bytes - 1) / layer_bytes, (49152 + bpl - 1) / bpl);
+    if (k >= g.D) return g.D;
+    const long long n = (g.D + k - 1) / k;
+    return (int)((g.D + n - 1) / n);
 }
 
 extern "C" {
@@ -268,14 +329,16 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     o.device = -1;
     o.plane_skew_bytes = -1;
     if (opts) {
-        if (opts->struct_size < (int)offsetof(lbm_opts, reserved) || opts->struct_size > (int)sizeof(lbm_opts))
+        if (opts->struct_size < (int)offsetof(lbm_opts, slide_chunk) || opts->struct_size > (int)sizeof(lbm_opts))
             return fail(nullptr, LBM_ERR_INVALID, "lbm_create: lbm_opts.struct_size %d not understood", opts->struct_size);
         memcpy(&o, opts, (size_t)opts->struct_size);
     }
     if (o.preset != LBM_PRESET_WIND_TUNNEL_REF && o.preset != LBM_PRESET_CAVITY)
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown preset %d", o.preset);
-    if (o.scheme != LBM_SCHEME_AB && o.scheme != LBM_SCHEME_AA)
+    if (o.scheme != LBM_SCHEME_AB && o.scheme != LBM_SCHEME_AA && o.scheme != LBM_SCHEME_SLIDE)
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
+    if (o.scheme == LBM_SCHEME_SLIDE && o.depth_global > 0)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: the sliding in-place scheme does not run as z-slabs (use LBM_SCHEME_AB or LBM_SCHEME_AA)");
     int Dg = o.depth_global > 0 ? o.depth_global : depth;
     int z0 = o.depth_global > 0 ? o.z0 : 0;
     if (z0 < 0 || (long long)z0 + depth > Dg)
@@ -312,6 +375,18 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     }
     c->layout = layout;
     const long long rows_per_layer = aa ? height + 2 : height;  // AA: ghost rows y = H and y = -1
+    const bool slide = o.scheme == LBM_SCHEME_SLIDE;
+    if (slide) {
+        if (o.slide_chunk < 0) { delete c; return fail(nullptr, LBM_ERR_INVALID, "lbm_create: slide_chunk %d", o.slide_chunk); }
+        // default: the measured-best launch size, but at most a quarter of the depth in spare layers
+        // (the scheme exists to save memory); slide_chunk / LBM_SLIDE_CHUNK override
+        c->slide_chunk = std::max(2, std::min(auto_chunk(g, g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0)), depth / 4));
+        if (o.slide_chunk > 0) c->slide_chunk = o.slide_chunk;
+        if (const char* t = getenv("LBM_SLIDE_CHUNK")) c->slide_chunk = std::max(1, atoi(t));
+        if (c->slide_chunk > depth) c->slide_chunk = depth;
+        if (const char* t = getenv("LBM_SLIDE_SKEW")) c->slide_skew = std::max(0ll, atoll(t)) / 128 * 32;
+    }
+    const long long layers = (long long)depth + 2 + (slide ? c->slide_chunk + 2 : 0);  // SLIDE: room for the shifted copy
     long long guard;                                             // AA: floats in front of plane 0 that (y = -1, z = -1) reaches
     if (layout == LBM_LAYOUT_ROWS) {
         long long row_pad = 0;
@@ -320,7 +395,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         g.row = (long long)Q * g.Wp + (row_pad > 0 ? row_pad : 0);
         g.layer = rows_per_layer * g.row;
         guard = aa ? g.row + 32 : 0;
-        c->pop_floats = (long long)(depth + 2) * g.layer;
+        c->pop_floats = layers * g.layer + c->slide_skew;
     } else {
         g.row = g.Wp;
         g.layer = rows_per_layer * g.Wp;
@@ -328,10 +403,11 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         guard = aa ? g.Wp + 32 : 0;
         if (skew_floats < guard) skew_floats = guard;
         skew_floats = (skew_floats + 31) / 32 * 32;                                          // keep rows 128-B aligned
-        g.plane = (long long)(depth + 2) * g.layer + skew_floats;
+        g.plane = layers * g.layer + skew_floats + c->slide_skew;
         c->pop_floats = (long long)Q * g.plane;
     }
     c->guard_floats = guard;
+    c->slide_shift = (long long)(c->slide_chunk + 2) * g.layer + c->slide_skew;
     c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
     // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
@@ -341,6 +417,9 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     // 5.5, with alternating z 6.03 -> plain nt/nt is the default there.
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
+    c->probe = getenv("LBM_PROBE") != nullptr;
+    c->ab_chunk = auto_chunk(g, c->segsx_log2);
+    if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
     c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
@@ -373,10 +452,22 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         CR(hipMalloc(&c->ob[1], ob_bytes));
         CR(hipMalloc(&c->prev_mask, mask_bytes));
         CR(hipMemsetAsync(c->prev_mask, 0, mask_bytes, c->stream));
+    } else if (slide) {
+        CR(hipMalloc(&c->f[0], c->pop_bytes));
+        const size_t ob_bytes = (size_t)OB_N * (depth + 2) * height * sizeof(float);
+        CR(hipMalloc(&c->ob[0], ob_bytes));
+        CR(hipMalloc(&c->ob[1], ob_bytes));
+    } else if (const char* t = getenv("LBM_AB_SINGLE")) {  // probe: both buffers in one allocation, a chosen distance apart
+        const long long skew = std::max(0ll, atoll(t)) / 128 * 32;
+        CR(hipMalloc(&c->alloc0, 2 * c->pop_bytes + (size_t)skew * sizeof(float)));
+        c->f[0] = c->alloc0;
+        c->f[1] = c->alloc0 + c->pop_floats + skew;
+        c->f1_in_alloc0 = true;
     } else {
         CR(hipMalloc(&c->f[0], c->pop_bytes));
         CR(hipMalloc(&c->f[1], c->pop_bytes));
     }
+    if (getenv("LBM_DEBUG_PTRS")) fprintf(stderr, "[lbm] f0=%p f1=%p pop_bytes=%zu\n", (void*)c->f[0], (void*)c->f[1], c->pop_bytes);
     CR(hipMalloc(&c->mask, mask_bytes));
     CR(hipMemsetAsync(c->mask, 0, mask_bytes, c->stream));  // d_solid.memset(0), lbm_solver.cu:415
     CR(hipMalloc(&c->flags, (size_t)depth * height * g.Wt));
@@ -392,7 +483,8 @@ int lbm_destroy(lbm_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->alloc0) hipFree(c->alloc0); else hipFree(c->f[0]);
-    hipFree(c->f[1]); hipFree(c->mask); hipFree(c->flags);
+    if (!c->f1_in_alloc0) hipFree(c->f[1]);
+    hipFree(c->mask); hipFree(c->flags);
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
     hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -410,11 +502,12 @@ int lbm_init(lbm_ctx* c) {
     hipLaunchKernelGGL(k_fill_planes, grid1(last - first), dim3(256), 0, c->stream, c->f[0],
                        c->f[1] ? c->f[1] : c->f[0], c->g, c->layout == LBM_LAYOUT_ROWS ? 1 : 0, first, last);
     HIPCHK(c, hipGetLastError());
-    if (c->scheme == LBM_SCHEME_AA) {
+    if (c->scheme != LBM_SCHEME_AB) {
         const long long per = (long long)(c->g.D + 2) * c->g.H;
         hipLaunchKernelGGL(k_ob_fill, grid1(per * OB_N), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
         HIPCHK(c, hipGetLastError());
         c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
+        c->slide_off = 0;
     }
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
     c->curl_valid = false;
@@ -559,9 +652,26 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         c->curl_valid = false;
         return LBM_OK;
     }
-    for (int s = 0; s < nsteps; s++) {
-        rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D);
+    if (c->scheme == LBM_SCHEME_SLIDE) {
+        rc = ensure_field_buffers(c);
+        for (int s = 0; s < nsteps && !rc; s++) rc = slide_step(c, s == nsteps - 1 && c->g.fnz > 0);
         if (rc) return rc;
+        c->p_last = c->p;
+        c->steps += (uint64_t)nsteps;
+        c->fields = FIELDS_VALID;
+        c->curl_valid = false;
+        return LBM_OK;
+    }
+    for (int s = 0; s < nsteps; s++) {
+        if (c->probe) { const char* t = getenv("LBM_AB_CHUNK"); c->ab_chunk = t ? std::max(0, atoi(t)) : 0; }
+        const int K = c->ab_chunk > 0 ? c->ab_chunk : c->g.D;
+        const int nchunks = (c->g.D + K - 1) / K;
+        const bool top_down = (c->tune & 4) && c->zrev;  // the launches follow the layer order inside a launch
+        for (int i = 0; i < nchunks; i++) {
+            const int zb = (top_down ? nchunks - 1 - i : i) * K;
+            rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1 + zb, std::min(K, c->g.D - zb));
+            if (rc) return rc;
+        }
         c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
         c->zrev ^= 1;
     }
@@ -730,7 +840,7 @@ static int copy_populations(lbm_ctx* c, float* host, bool to_host) {
     const Geo& g = c->g;
     const size_t n = (size_t)cells(c);
     for (int k = 0; k < Q; k++) {
-        float* dev = c->f[c->cur] + (long long)k * g.plane + g.layer;  // first owned layer
+        float* dev = current_populations(c) + (long long)k * g.plane + g.layer;  // first owned layer
         float* h = host + (size_t)k * n;
         if (to_host)
             HIPCHK(c, hipMemcpy2DAsync(h, (size_t)g.W * 4, dev, (size_t)g.row * 4, (size_t)g.W * 4, (size_t)g.H * g.D, hipMemcpyDeviceToHost, c->stream));
@@ -786,6 +896,12 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     }
     rc = copy_populations(c, const_cast<float*>(f), false);
     if (rc) return rc;
+    if (c->scheme == LBM_SCHEME_SLIDE) {  // the outlet column's side array follows the new populations
+        hipLaunchKernelGGL(k_ob_gather, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
+                           current_populations(c), c->ob[0], c->ob[1], c->g);
+        HIPCHK(c, hipGetLastError());
+        return LBM_OK;
+    }
     c->mask_dirty = true;  // solid cells of the other buffer must follow
     return LBM_OK;
 }
@@ -827,7 +943,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->steps = c->steps;
     out->cells = (uint64_t)cells(c);
     out->bytes_per_cell = 2ull * Q * sizeof(float);
-    out->population_bytes = (c->scheme == LBM_SCHEME_AA ? 1ull : 2ull) * c->pop_bytes;
+    out->population_bytes = (c->scheme == LBM_SCHEME_AB ? 2ull : 1ull) * c->pop_bytes;
     out->last_timed_ms = c->last_ms;
     out->last_timed_steps = c->last_steps;
     return LBM_OK;
@@ -898,6 +1014,7 @@ int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
 
 static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
     if (!c->g.slab) return fail(c, LBM_ERR_STATE, "%s: context was not created as a slab (lbm_opts.depth_global = 0)", who);
+    if (c->scheme == LBM_SCHEME_SLIDE) return fail(c, LBM_ERR_STATE, "%s: the sliding in-place scheme does not run as z-slabs", who);
     if (side != 0 && side != 1) return fail(c, LBM_ERR_INVALID, "%s: side must be 0 or 1", who);
     if (!p) return fail(c, LBM_ERR_INVALID, "%s: buffer is null", who);
     return LBM_OK;
@@ -970,6 +1087,7 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
 int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
     NEED(c);
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
+    if (c->scheme == LBM_SCHEME_SLIDE) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: the sliding in-place scheme has no split step");
     if ((d_msg_bottom || d_msg_top) && !c->g.slab)
         return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: messages need a slab context");
     const bool was_dirty = c->mask_dirty;

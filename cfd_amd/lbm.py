@@ -15,6 +15,7 @@ PRESET_WIND_TUNNEL = 0
 PRESET_CAVITY = 1
 SCHEME_AB = 0
 SCHEME_AA = 1
+SCHEME_SLIDE = 2
 LAYOUT_DEFAULT = 0
 LAYOUT_PLANES = 1
 LAYOUT_ROWS = 2
@@ -34,7 +35,7 @@ class Opts(C.Structure):
                 ("scheme", C.c_int32), ("z0", C.c_int32), ("depth_global", C.c_int32),
                 ("stream", C.c_void_p), ("plane_skew_bytes", C.c_int32),
                 ("layout", C.c_int32), ("boundary_stream", C.c_void_p),
-                ("reserved", C.c_int32 * 4)]
+                ("slide_chunk", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Stats(C.Structure):
@@ -132,7 +133,7 @@ class Solver:
 
     def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
                  stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB, boundary_stream=None,
-                 layout=LAYOUT_DEFAULT):
+                 layout=LAYOUT_DEFAULT, slide_chunk=0):
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
@@ -149,6 +150,7 @@ class Solver:
         o.plane_skew_bytes = plane_skew_bytes
         o.layout = layout
         o.boundary_stream = boundary_stream
+        o.slide_chunk = slide_chunk
         self._ctx = _ctx()
         rc = self._lib.lbm_create(C.byref(self._ctx), W, H, D, C.byref(o))
         if rc != 0:

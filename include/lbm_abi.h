@@ -56,8 +56,14 @@ enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
  * neighbour read / neighbour write): same results, half the population memory; rho/u are written
  * by the last step of each lbm_step() call; a cell that a later mask change turns from solid back
  * to fluid restarts from equilibrium (there is no second buffer to keep its frozen values).
- * Both schemes run as z-slabs. */
-enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1 };
+ * Both schemes run as z-slabs.
+ * SLIDE = the A/B kernel on ONE buffer with chunk + 2 spare layers: a step reads the lattice at one
+ * layer offset and writes it at the other, a chunk of layers per launch, in the direction of the
+ * shift, so a launch never overwrites what it or a later launch still reads.  Same results, the
+ * A/B kernel's aligned access pattern, 1/2 + (chunk + 2)/(2 D) of the memory; a solid cell's frozen
+ * populations move with the lattice, so every result equals A/B's, solid cells included; rho/u are
+ * written by the last step of each lbm_step() call as in AA; it does not run as z-slabs. */
+enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1, LBM_SCHEME_SLIDE = 2 };
 
 /* Population storage in HBM (fp32 SoA rows padded to 128-byte lines either way):
  *   PLANES [k][z][y][x]  19 separate planes, skewed against each other;
@@ -81,7 +87,8 @@ typedef struct lbm_opts {
      * boundary layers and the halo exchange run beside the interior update instead of in front of
      * it; the CALLER orders the two streams (see cfd_amd/slab.py).  NULL = use `stream`. */
     void*   boundary_stream;
-    int32_t reserved[4];
+    int32_t slide_chunk;   /* LBM_SCHEME_SLIDE: layers per launch (spare layers = chunk + 2); 0 = library default (32) */
+    int32_t reserved[3];
 } lbm_opts;
 
 /* Per-context counters for benches (device time is measured with HIP events on the

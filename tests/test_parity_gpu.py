@@ -226,3 +226,19 @@ def test_derived_fields(oracle, lbm):
     np.testing.assert_array_equal(g.velocity_strided(3, 3, 2), u[5:11][::2, ::3, ::3])
     with pytest.raises(lbm.LbmError):
         g.velocity_strided(0, 1, 1)
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 7])
+def test_ab_layers_per_launch(oracle, lbm, chunk, monkeypatch):
+    """a step cut into launches of `chunk` layers (the library does this on its own for large domains,
+    lbm_hip.hip auto_chunk) gives the same bits as one launch"""
+    monkeypatch.setenv("LBM_AB_CHUNK", str(chunk))
+    W, H, D = 70, 12, 16
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D)
+    for s in (o, g):
+        s.init(); s.add_solid(20, 0, 3, 9, 7, 9); s.add_solid(W - 3, 2, D - 2, 3, 5, 2)
+    o.step(5); g.step(5)
+    np.testing.assert_array_equal(g.density(), o.density())
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    np.testing.assert_array_equal(g.populations(), o.populations())
