@@ -79,6 +79,7 @@ struct lbm_ctx {
     int slide_chunk = 0;     // SLIDE: layers per launch; the lattice moves by slide_chunk + 2 layers per step
     bool f1_in_alloc0 = false;
     bool probe = false;        // LBM_PROBE=1: launch knobs are re-read from the environment at every lbm_step (tuning probes)
+    int aa_chunk = 0;        // AA: layers per launch (0 = the whole domain in one launch)
     int ab_chunk = 0;        // A/B: layers per launch (0 = the whole domain in one launch)
     long long slide_off = 0;   // SLIDE: offset (floats) of the lattice inside the buffer right now: 0 or slide_shift
     long long slide_shift = 0; // SLIDE: (chunk + 2) layers + slide_skew
@@ -210,14 +211,29 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     return LBM_OK;
 }
 
+// A/B update of layers [zl_begin, zl_begin + nlayers) in launches of ab_chunk layers (see auto_chunk())
+static int launch_ab_layers(lbm_ctx* c, int zl_begin, int nlayers) {
+    if (c->probe) { const char* t = getenv("LBM_AB_CHUNK"); c->ab_chunk = t ? std::max(0, atoi(t)) : 0; }
+    const int K = c->ab_chunk > 0 ? c->ab_chunk : nlayers;
+    const int nchunks = (nlayers + K - 1) / K;
+    const bool top_down = (c->tune & 4) && c->zrev;  // the launches follow the layer order inside a launch
+    for (int i = 0; i < nchunks; i++) {
+        const int zb = (top_down ? nchunks - 1 - i : i) * K;
+        int rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, zl_begin + zb, std::min(K, nlayers - zb));
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
+
 // one AA launch over layers [zl_begin, zl_begin + nlayers), or over the two layers zl_begin and
 // zl_second when zl_second > 0; the caller flips the phase with aa_flip() once the step is complete
-static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, int zl_second, hipStream_t stream = nullptr) {
+static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, int zl_second, hipStream_t stream = nullptr,
+                     bool whole_step = false) {
     if (nlayers <= 0) return LBM_OK;
     if (!stream) stream = c->stream;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
-    const int zrev = ((c->tune & 4) && nlayers == c->g.D) ? c->zrev : 0;
+    const int zrev = ((c->tune & 4) && (whole_step || nlayers == c->g.D)) ? c->zrev : 0;
 #define LBM_AA(PRESET, PHASE, TUNE)                                                                               \
     hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, stream, c->f[0], c->ob[c->ob_cur],     \
                        c->ob[1 - c->ob_cur], c->mask, c->flags, c->rho, c->u, c->g, c->p, c->segsx_log2, zrev,     \
@@ -244,8 +260,22 @@ static void aa_flip(lbm_ctx* c) {
     c->ob_cur ^= 1;
     c->zrev ^= 1;
 }
+// AA update of layers [zl_begin, zl_begin + nlayers) in launches of aa_chunk layers (auto_chunk():
+// 1024x512x512 runs 8 % faster in launches of 8-16 layers than in one, 4.95 -> 5.38 TB/s)
+static int launch_aa_layers(lbm_ctx* c, int want_moments, int zl_begin, int nlayers) {
+    if (c->probe) { const char* t = getenv("LBM_AB_CHUNK"); c->aa_chunk = t ? std::max(0, atoi(t)) : 0; }
+    const int K = c->aa_chunk > 0 ? c->aa_chunk : nlayers;
+    const int nchunks = (nlayers + K - 1) / K;
+    const bool top_down = (c->tune & 4) && c->zrev;
+    for (int i = 0; i < nchunks; i++) {
+        const int zb = (top_down ? nchunks - 1 - i : i) * K;
+        int rc = launch_aa(c, want_moments, zl_begin + zb, std::min(K, nlayers - zb), 0, nullptr, true);
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
 static int launch_aa_step(lbm_ctx* c, int want_moments) {
-    int rc = launch_aa(c, want_moments, 1, c->g.D, 0);
+    int rc = launch_aa_layers(c, want_moments, 1, c->g.D);
     if (!rc) aa_flip(c);
     return rc;
 }
@@ -418,8 +448,8 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
     c->probe = getenv("LBM_PROBE") != nullptr;
-    c->ab_chunk = auto_chunk(g, c->segsx_log2);
-    if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = std::max(0, atoi(t));
+    c->ab_chunk = c->aa_chunk = auto_chunk(g, c->segsx_log2);
+    if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = c->aa_chunk = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
     c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
@@ -663,15 +693,8 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         return LBM_OK;
     }
     for (int s = 0; s < nsteps; s++) {
-        if (c->probe) { const char* t = getenv("LBM_AB_CHUNK"); c->ab_chunk = t ? std::max(0, atoi(t)) : 0; }
-        const int K = c->ab_chunk > 0 ? c->ab_chunk : c->g.D;
-        const int nchunks = (c->g.D + K - 1) / K;
-        const bool top_down = (c->tune & 4) && c->zrev;  // the launches follow the layer order inside a launch
-        for (int i = 0; i < nchunks; i++) {
-            const int zb = (top_down ? nchunks - 1 - i : i) * K;
-            rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1 + zb, std::min(K, c->g.D - zb));
-            if (rc) return rc;
-        }
+        rc = launch_ab_layers(c, 1, c->g.D);
+        if (rc) return rc;
         c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
         c->zrev ^= 1;
     }
@@ -1137,8 +1160,8 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
 int lbm_step_interior_layers(lbm_ctx* c) {
     NEED(c);
     if (c->split_phase != 1) return fail(c, LBM_ERR_STATE, "lbm_step_interior_layers: call lbm_step_boundary_layers first");
-    int rc = c->scheme == LBM_SCHEME_AA ? launch_aa(c, c->g.fnz > 0, 2, c->g.D - 2, 0)
-                                        : launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 2, c->g.D - 2);
+    int rc = c->scheme == LBM_SCHEME_AA ? launch_aa_layers(c, c->g.fnz > 0, 2, c->g.D - 2)
+                                        : launch_ab_layers(c, 2, c->g.D - 2);
     if (rc) return rc;
     c->split_phase = 2;
     return LBM_OK;

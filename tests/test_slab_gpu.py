@@ -70,8 +70,11 @@ def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm, scheme):
         np.testing.assert_array_equal(f, o.populations(), err_msg=str(splits))
 
 
+@pytest.mark.parametrize("chunk", [0, 5])
 @pytest.mark.parametrize("scheme", [0, 1])
-def test_slabs_cube_64(oracle, lbm, scheme):
+def test_slabs_cube_64(oracle, lbm, scheme, chunk, monkeypatch):
+    """chunk 5: the interior update of every slab in launches of 5 layers (lbm_hip.hip auto_chunk)"""
+    monkeypatch.setenv("LBM_AB_CHUNK", str(chunk))
     o = oracle.Solver(64, 64, 64)
     o.init(); o.load_mesh(CUBE_OBJ)
     mask = o.solid_mask()
