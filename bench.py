@@ -13,7 +13,8 @@ send/recv (torch.distributed backend "nccl"), overlapped with the interior updat
 --config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised
 car stand-in (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
 --config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
---config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), weak scaling over z-slabs.
+--config 4: configs[4], in-place scheme sized to HBM (~3.4 G cells per GPU): the sliding A/B scheme on one
+GPU, AA (the in-place scheme that runs as z-slabs) for weak scaling over N > 1.
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the solver's stream;
 `cpu_baseline` times the CPU oracle (a port of the reference update: the reference has no CPU path)
 on a bounded sample of the same workload, on rank 0 at N = 1 only.
@@ -108,12 +109,14 @@ def main():
     cfg = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
            2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
            3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
-           4: ((1504, 1536, 1484), "wind_tunnel", "aa", None, "weak")}[args.config]
+           4: ((1504, 1536, 1484), "wind_tunnel", "slide", None, "weak")}[args.config]
     size, preset_name, scheme_name, obstacle, scaling = cfg
     if args.size:
         size = tuple(args.size)
     preset_name = args.preset or preset_name
     scheme_name = args.scheme or scheme_name
+    if scheme_name == "slide" and (world > 1 or args.rehearse_slab) and not args.scheme:
+        scheme_name = "aa"   # the sliding scheme does not run as z-slabs; AA is the in-place scheme that does
     W, H, D = size
     if scaling == "strong":
         if D % world:
@@ -173,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     step(args.steps)
     dev_ms = solver.timer_end()                 # HIP events on the solver's stream
+    launches = max(1, solver.stats()["last_timed_launches"])   # a step is cut into launches of ~1 GB of traffic
     fence()
     dt = time.perf_counter() - t0
 
@@ -195,7 +199,9 @@ def main():
     # dominant kernel: k_stream_collide; one launch per step at N=1 (three at N>1: 2 boundary
     # layers + interior); achieved = algorithmic bytes per step / device time per step
     dev_ms_per_step = dev_ms / args.steps
-    achieved = fluid * BYTES_PER_CELL / (dev_ms_per_step * 1e-3) / 1e9
+    launch_ms = dev_ms / launches
+    bytes_per_launch = fluid * BYTES_PER_CELL * args.steps / launches
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -223,9 +229,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide",
-                         "launch_ms": round(dev_ms_per_step, 5),
-                         "algorithmic_bytes_per_launch": fluid * BYTES_PER_CELL,
-                         "fluid_cells_per_launch": fluid},
+                         "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches / args.steps, 3),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                         "fluid_cells_per_launch": round(fluid * args.steps / launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             solver.close()

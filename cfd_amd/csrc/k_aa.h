@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256) void k_aa_step(
     const unsigned long long* __restrict__ mask, const unsigned char* __restrict__ flags,
     float* __restrict__ rho_out, float4* __restrict__ u_out, Geo g, Params p, int segsx_log2, int zrev,
     int want_moments, int zl_begin, int zl_second) {
-    const TileId t = tile_of_wave(segsx_log2);
+    const TileId t = tile_of_wave(segsx_log2, zrev);
     const int y = t.y;
     // zl_second > 0: the two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
-    const int zl = zl_second > 0 ? (blockIdx.z == 0 ? zl_begin : zl_second)
-                                 : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    const int zl = zl_second > 0 ? (t.bz == 0 ? zl_begin : zl_second)
+                                 : zl_begin + ((zrev & ZORDER_REVERSE) ? (int)(gridDim.z - 1 - t.bz) : t.bz);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];

@@ -274,16 +274,35 @@ struct GatherAll<PRESET, -1> {
 
 // Tile -> (xs, y, z) mapping shared by the kernels that walk tiles: a 256-thread block is four
 // waves; `segsx` of them sit side by side in x, the rest stack in y.
+// The hardware deals workgroups out to the 8 XCDs round-robin in launch order (x fastest), so the
+// workgroups that sit side by side in one row land on different XCDs and the cache line their
+// x-shifted loads share at the seam is fetched into two L2s.  With ZORDER_XCD the launch order is
+// re-read so that each XCD gets whole rows: of every 8 consecutive rows of workgroups, row j goes to XCD j.
+constexpr int ZORDER_REVERSE = 1, ZORDER_XCD = 2;
 struct TileId {
-    int xs, y, lane;
+    int xs, y, lane, bz;
 };
-__device__ __forceinline__ TileId tile_of_wave(int segsx_log2) {
+__device__ __forceinline__ TileId tile_of_wave(int segsx_log2, int zorder) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TileId t;
     t.lane = threadIdx.x & 63;
     const int segsx = 1 << segsx_log2;
-    t.xs = blockIdx.x * segsx + (wave & (segsx - 1));
-    t.y = blockIdx.y * (4 >> segsx_log2) + (wave >> segsx_log2);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((zorder & ZORDER_XCD) && gridDim.x > 1) {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned rows = gy * gridDim.z;                     // rows of workgroups in this launch
+        const unsigned L = bx + gx * (by + gy * bz);              // launch order
+        const unsigned group = L / (8 * gx), within = L - group * (8 * gx);
+        if (group * 8 + 8 <= rows) {                              // the ragged tail keeps the launch order
+            const unsigned R = group * 8 + (within & 7);
+            bx = within >> 3;
+            bz = R / gy;
+            by = R - bz * gy;
+        }
+    }
+    t.xs = bx * segsx + (wave & (segsx - 1));
+    t.y = by * (4 >> segsx_log2) + (wave >> segsx_log2);
+    t.bz = bz;
     return t;
 }
 
@@ -322,12 +341,12 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
     int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top,
     const float* __restrict__ ob_old, float* __restrict__ ob_new, int want_moments) {
-    const TileId t = tile_of_wave(segsx_log2);
+    const TileId t = tile_of_wave(segsx_log2, zrev);
     const int y = t.y;
     // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
     // starts on the layers the previous step wrote last (still in the Infinity Cache)
-    const int zl = MODE == 2 ? (blockIdx.z == 0 ? zl_begin : zl_second)
-                             : zl_begin + (zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z);
+    const int zl = MODE == 2 ? (t.bz == 0 ? zl_begin : zl_second)
+                             : zl_begin + ((zrev & ZORDER_REVERSE) ? (int)(gridDim.z - 1 - t.bz) : t.bz);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];

@@ -78,6 +78,7 @@ struct lbm_ctx {
     int aa_phase = 0;          // AA: 0 = next step is even (buffer in the streamed layout)
     int slide_chunk = 0;     // SLIDE: layers per launch; the lattice moves by slide_chunk + 2 layers per step
     bool f1_in_alloc0 = false;
+    bool xcd_rows = false;     // ZORDER_XCD: whole rows of workgroups per XCD (k_step.h tile_of_wave)
     bool probe = false;        // LBM_PROBE=1: launch knobs are re-read from the environment at every lbm_step (tuning probes)
     int aa_chunk = 0;        // AA: layers per launch (0 = the whole domain in one launch)
     int ab_chunk = 0;        // A/B: layers per launch (0 = the whole domain in one launch)
@@ -91,6 +92,7 @@ struct lbm_ctx {
     size_t mask_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint64_t steps = 0, steps_at_begin = 0;
+    uint64_t launches = 0, launches_at_begin = 0, last_launches = 0;  // step-kernel launches (a step may take several)
     double last_ms = 0.0;
     uint64_t last_steps = 0;
     size_t pop_bytes = 0;
@@ -191,7 +193,8 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
     hipStream_t stream = (MODE == 2 && c->stream_b) ? c->stream_b : c->stream;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
-    const int zrev = (MODE == 0 && (c->tune & 4)) ? c->zrev : 0;
+    if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
+    const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0);
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
     hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
                        c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top,     \
@@ -208,6 +211,7 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
 #undef LBM_LAUNCH_T
 #undef LBM_LAUNCH
     HIPCHK(c, hipGetLastError());
+    if (MODE != 1) c->launches++;
     return LBM_OK;
 }
 
@@ -233,7 +237,8 @@ static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, in
     if (!stream) stream = c->stream;
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
-    const int zrev = ((c->tune & 4) && (whole_step || nlayers == c->g.D)) ? c->zrev : 0;
+    if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
+    const int zrev = (((c->tune & 4) && (whole_step || nlayers == c->g.D)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0);
 #define LBM_AA(PRESET, PHASE, TUNE)                                                                               \
     hipLaunchKernelGGL((k_aa_step<PRESET, PHASE, TUNE>), grid, dim3(256), 0, stream, c->f[0], c->ob[c->ob_cur],     \
                        c->ob[1 - c->ob_cur], c->mask, c->flags, c->rho, c->u, c->g, c->p, c->segsx_log2, zrev,     \
@@ -253,6 +258,7 @@ static int launch_aa(lbm_ctx* c, int want_moments, int zl_begin, int nlayers, in
 #undef LBM_AA_T
 #undef LBM_AA
     HIPCHK(c, hipGetLastError());
+    c->launches++;
     return LBM_OK;
 }
 static void aa_flip(lbm_ctx* c) {
@@ -331,13 +337,13 @@ static int materialise_fields(lbm_ctx* c) {
 // Layers per launch.  Measured on MI355X (profiles/r01_tuning.md, "layers per launch"): a step cut into
 // launches of about 1 GB of algorithmic traffic runs 2-4 % faster than one launch over the whole
 // domain (256^3: 6.09 -> 6.27 TB/s at 96 layers, 512x256x256: 5.75 -> 5.98 at 32-64, 1024x512x512:
-// 5.96 -> 6.08 at 16-32), as long as a launch keeps >= 48 K workgroups or so in flight
-// (2048x1024x128 loses 1-2 % below 8 layers).  Chunks are balanced over the depth.
+// 5.96 -> 6.08 at 16-32), as long as a launch keeps >= 32 K workgroups or so
+// (2048x1024x128 loses 1-2 % below 8 layers; 1504x1536x1484 in place is best at 2-4 layers).  Chunks are balanced over the depth.
 static int auto_chunk(const Geo& g, int segsx_log2) {
     const int segsx = 1 << segsx_log2;
     const long long bpl = (long long)((g.Wt + segsx - 1) / segsx) * ((g.H + (4 / segsx) - 1) / (4 / segsx));  // workgroups per layer
     const long long layer_bytes = (long long)g.W * g.H * 152;
-    long long k = std::max(((1ll << 30) + layer_bytes - 1) / layer_bytes, (49152 + bpl - 1) / bpl);
+    long long k = std::max(((1ll << 30) + layer_bytes - 1) / layer_bytes, (32768 + bpl - 1) / bpl);
     if (k >= g.D) return g.D;
     const long long n = (g.D + k - 1) / k;
     return (int)((g.D + n - 1) / n);
@@ -439,6 +445,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->guard_floats = guard;
     c->slide_shift = (long long)(c->slide_chunk + 2) * g.layer + c->slide_skew;
     c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
+    if (const char* t = getenv("LBM_SEGSX")) c->segsx_log2 = std::min(c->segsx_log2, std::max(0, atoi(t)));
     // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
     // In place (AA) the write-through stores lose: partial-line neighbour writes no longer combine
@@ -448,6 +455,14 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
     c->probe = getenv("LBM_PROBE") != nullptr;
+    {   // Workgroups go to the 8 XCDs round-robin in launch order.  When the workgroups per row divide 8
+        // (W <= 2048 in powers of two) that hands every XCD a fixed x segment, which runs well; otherwise
+        // (e.g. W = 1504: 6 per row) the assignment wanders, and giving each XCD whole rows is 2 % faster
+        // for the pull kernel (5.77 -> 5.92 TB/s at 1504x1536; AA loses 1 %, tools/xcd_rows_probe.py).
+        const int segsx = 1 << c->segsx_log2, gx = (g.Wt + segsx - 1) / segsx;
+        c->xcd_rows = o.scheme != LBM_SCHEME_AA && 8 % gx != 0;
+    }
+    if (const char* t = getenv("LBM_XCD_ROWS")) c->xcd_rows = atoi(t) != 0;
     c->ab_chunk = c->aa_chunk = auto_chunk(g, c->segsx_log2);
     if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = c->aa_chunk = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
@@ -969,6 +984,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->population_bytes = (c->scheme == LBM_SCHEME_AB ? 2ull : 1ull) * c->pop_bytes;
     out->last_timed_ms = c->last_ms;
     out->last_timed_steps = c->last_steps;
+    out->last_timed_launches = c->last_launches;
     return LBM_OK;
 }
 
@@ -977,6 +993,7 @@ int lbm_timer_begin(lbm_ctx* c) {
     int rc = refresh_mask_state(c);  // keep one-off set-up kernels out of the timed region
     if (rc) return rc;
     c->steps_at_begin = c->steps;
+    c->launches_at_begin = c->launches;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return LBM_OK;
 }
@@ -989,6 +1006,7 @@ int lbm_timer_end(lbm_ctx* c) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
     c->last_steps = c->steps - c->steps_at_begin;
+    c->last_launches = c->launches - c->launches_at_begin;
     return LBM_OK;
 }
 

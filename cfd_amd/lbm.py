@@ -41,7 +41,7 @@ class Opts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("steps", C.c_uint64), ("cells", C.c_uint64), ("bytes_per_cell", C.c_uint64),
                 ("population_bytes", C.c_uint64), ("last_timed_ms", C.c_double),
-                ("last_timed_steps", C.c_uint64)]
+                ("last_timed_steps", C.c_uint64), ("last_timed_launches", C.c_uint64)]
 
 
 # every symbol include/lbm_abi.h declares, with its ctypes signature

@@ -100,6 +100,8 @@ typedef struct lbm_stats {
     uint64_t population_bytes;  /* device bytes held by the population buffers */
     double   last_timed_ms;     /* device ms between the last timer_begin/timer_end pair */
     uint64_t last_timed_steps;  /* steps issued between them */
+    uint64_t last_timed_launches; /* step-kernel launches issued between them (large domains step in several
+                                   * launches of about 1 GB of traffic each, slabs in boundary + interior launches) */
 } lbm_stats;
 
 /* lbm_solver::lbm_solver(int,int,int)  -- lbm_solver.cu:404-453.  opts may be NULL. */

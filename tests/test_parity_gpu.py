@@ -244,3 +244,23 @@ def test_layers_per_launch(oracle, lbm, chunk, scheme, monkeypatch):
     np.testing.assert_array_equal(g.velocity(), o.velocity())
     fluid = o.solid_mask() == 0
     np.testing.assert_array_equal(g.populations()[:, fluid], o.populations()[:, fluid])
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+@pytest.mark.parametrize("dims", [(600, 10, 9), (130, 7, 5), (390, 3, 3)])
+def test_xcd_row_order(oracle, lbm, dims, scheme, monkeypatch):
+    """ZORDER_XCD (k_step.h tile_of_wave): the launch order re-read so that each XCD gets whole rows of
+    workgroups -- a permutation of the workgroups, incl. the ragged tail of a launch whose row count
+    is no multiple of 8; the library switches it on by itself for widths such as 1504"""
+    monkeypatch.setenv("LBM_XCD_ROWS", "1")
+    monkeypatch.setenv("LBM_AB_CHUNK", "4")
+    W, H, D = dims
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D, scheme=scheme)
+    for s in (o, g):
+        s.init(); s.add_solid(W // 3, 0, 1, 40, 2, 2); s.add_solid(W - 3, 1, D - 2, 3, 2, 2)
+    o.step(4); g.step(4)
+    np.testing.assert_array_equal(g.density(), o.density())
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    fluid = o.solid_mask() == 0
+    np.testing.assert_array_equal(g.populations()[:, fluid], o.populations()[:, fluid])

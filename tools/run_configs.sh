@@ -6,9 +6,13 @@ out=gpurun_out/configs.jsonl
 run() { t=$1; shift; timeout -k 10 $t python -u bench.py "$@" >> $out 2>> gpurun_out/configs.err || exit 1; }
 run 300 --config 1
 run 300 --config 1 --scheme aa --no-cpu-baseline
+run 300 --config 1 --scheme slide --no-cpu-baseline
 run 300 --config 1 --preset wind_tunnel --no-cpu-baseline
 run 300 --config 2 --steps 100
 run 300 --config 2 --steps 100 --scheme aa --no-cpu-baseline
+run 300 --config 2 --steps 100 --scheme slide --no-cpu-baseline
 run 400 --config 3 --steps 30 --warmup 5
 run 400 --config 3 --steps 30 --warmup 5 --scheme aa --no-cpu-baseline
+run 400 --config 3 --steps 30 --warmup 5 --scheme slide --no-cpu-baseline
 run 600 --config 4 --steps 20 --warmup 3
+run 600 --config 4 --steps 20 --warmup 3 --scheme aa --no-cpu-baseline
