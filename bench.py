@@ -115,8 +115,6 @@ def main():
         size = tuple(args.size)
     preset_name = args.preset or preset_name
     scheme_name = args.scheme or scheme_name
-    if scheme_name == "slide" and (world > 1 or args.rehearse_slab) and not args.scheme:
-        scheme_name = "aa"   # the sliding scheme does not run as z-slabs; AA is the in-place scheme that does
     W, H, D = size
     if scaling == "strong":
         if D % world:
@@ -131,8 +129,6 @@ def main():
 
     dist = None
     if world > 1 or args.rehearse_slab:
-        if scheme == lbm.SCHEME_SLIDE:
-            raise SystemExit("--scheme slide does not run as z-slabs (use ab or aa)")
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -145,8 +141,8 @@ def main():
         # than one stream whenever a rank has a neighbour, tools/rccl_self_probe.py)
         eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme, two_streams=True)
         solver = eng.solver
-        if scheme == lbm.SCHEME_AA:
-            # the in-place scheme writes rho/u of the field window in every split step: keep it small
+        if scheme != lbm.SCHEME_AB:
+            # the in-place schemes write rho/u of the field window in every split step: keep it small
             solver.set_field_window(0, min(4, D))
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()

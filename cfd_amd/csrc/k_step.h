@@ -202,13 +202,16 @@ __device__ __forceinline__ float gather_general(const Geo& g, const float* __res
     const int pl = code == SRC_CEIL_RFY ? RFY[K] : (code == SRC_SIDE_RFZ ? RFZ[K] : (code == SRC_INLET ? K : INV[K]));
     long long a = (long long)pl * g.plane + own;
     if (code == SRC_PULL) a = (long long)K * g.plane + own - ((long long)CZ[K] * g.layer + (long long)CY[K] * g.row + CX[K]);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && !OB) {
+    // sliding in-place scheme, undecomposed: the wrapped outlet index (Q2) would read layers the sweep
+    // has overwritten, so the column's values of the previous step come from the side array.  A slab
+    // finds the wrapped layer in its ghost layer like A/B does.
+    const bool side_array = OB && !g.slab;
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && !side_array) {
         const long long ao = outlet_off<K>(g, y, zl);  // wave-uniform
         if (code == SRC_OUTLET) a = ao;
     }
     float v = fin[a];
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && OB) {
-        // sliding in-place scheme: the column's values of the previous step come from the side array
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1 && side_array) {
         // (an outlet lane loaded its own slot above and discards it)
         if (code == SRC_OUTLET) v = aa_outlet_read<K>(g, ob_old, y, zl);
     }
@@ -314,7 +317,9 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2, int zorder) {
 // MODE 3: step of the sliding in-place scheme (LBM_SCHEME_SLIDE): fin and fout are the SAME buffer
 //         at different layer offsets, launched chunk by chunk (see slide_step() on the host); the
 //         outlet branch reads the side array, x = W-1 cells write it, and rho/u are written here
-//         when asked for (there is no intact previous buffer to recompute them from).
+//         when asked for (there is no intact previous buffer to recompute them from).  As a z-slab it
+//         writes the halo messages of the boundary layers like MODE 2; with fout == nullptr it ONLY
+//         writes messages (the boundary layer that the directed sweep reaches last must send early).
 // ------------------------------------------------------------------------------------------
 // message layout: see k_halo_pack
 __device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
@@ -374,11 +379,11 @@ __global__ __launch_bounds__(256) void k_stream_collide(
 #pragma unroll
                 for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
             }
-            if (MODE == 2) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
+            if (MODE == 2 || MODE == 3) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
                 if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
                 if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
             }
-            if (MODE == 3) {  // the lattice moves: a solid cell's frozen populations move with it
+            if (MODE == 3 && fout) {  // the lattice moves: a solid cell's frozen populations move with it
 #pragma unroll
                 for (int k = 0; k < Q; k++) fout[(long long)k * g.plane + own] = f[k];
             }
@@ -396,14 +401,16 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     }
     float o[Q];
     collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
-    float* dst = fout + own;
+    if (MODE != 3 || fout) {  // MODE 3 without fout: message-only pass over a slab-boundary layer
+        float* dst = fout + own;
 #pragma unroll
-    for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
-    if (MODE == 2) {
+        for (int k = 0; k < Q; k++) stf<TUNE>(dst + (long long)k * g.plane, o[k]);
+    }
+    if (MODE == 2 || MODE == 3) {
         if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, o);
         if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, o);
     }
-    if (MODE == 3 && x == g.W - 1) {
+    if (MODE == 3 && !g.slab && x == g.W - 1) {
 #pragma unroll
         for (int i = 0; i < OB_N; i++) ob_new[ob_at(g, i, zl - 1, y)] = o[OB_PLANE[i]];
     }

@@ -173,9 +173,11 @@ static int refresh_mask_state(lbm_ctx* c) {
     } else if (c->scheme == LBM_SCHEME_SLIDE) {
         // solid cells are carried along by the step itself (k_stream_collide MODE 3); only the outlet
         // column's side array needs the frozen values in both of its buffers
-        hipLaunchKernelGGL(k_ob_sync, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
-                           c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
-        HIPCHK(c, hipGetLastError());
+        if (c->ob[0]) {
+            hipLaunchKernelGGL(k_ob_sync, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
+                               c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
+            HIPCHK(c, hipGetLastError());
+        }
     } else {
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream,
                            c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
@@ -188,9 +190,9 @@ static int refresh_mask_state(lbm_ctx* c) {
 template <int MODE>
 static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers,
                                  int zl_second = 0, float* msg_bottom = nullptr, float* msg_top = nullptr,
-                                 int want_moments = 0) {
+                                 int want_moments = 0, hipStream_t on_stream = nullptr) {
     if (nlayers <= 0) return LBM_OK;
-    hipStream_t stream = (MODE == 2 && c->stream_b) ? c->stream_b : c->stream;
+    hipStream_t stream = on_stream ? on_stream : ((MODE == 2 && c->stream_b) ? c->stream_b : c->stream);
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
     if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
@@ -295,21 +297,44 @@ static int launch_aa_step(lbm_ctx* c, int want_moments) {
 // So the update has the access pattern of the A/B kernel (aligned stores, pulled loads) with
 // 1 + S/D of one buffer instead of two.  The outlet branch, which would read layers the sweep has
 // overwritten (quirk Q2 wraps to the far end), goes through the `ob` side array as in AA.
-static int slide_step(lbm_ctx* c, int want_moments) {
-    const int K = c->slide_chunk, D = c->g.D;
-    const bool up = c->slide_off == 0;
-    const float* fin = c->f[0] + c->slide_off;
-    float* fout = c->f[0] + (up ? c->slide_shift : 0);
-    const int nchunks = (D + K - 1) / K;
+//
+// As a z-slab the sweep keeps its direction, so only the boundary layer the sweep STARTS with can be
+// updated ahead of the interior; the other one gets a message-only pass first (it reads three input
+// layers and writes nothing but its halo message) and its real update after the interior.  The
+// incoming messages go into the ghost layers of the NEW lattice position once the interior has
+// consumed the input layers that lie there (lbm_halo_unpack_both runs behind the interior).
+static inline bool slide_up(const lbm_ctx* c) { return c->slide_off == 0; }
+static inline const float* slide_in(const lbm_ctx* c) { return c->f[0] + c->slide_off; }
+static inline float* slide_out(const lbm_ctx* c) { return c->f[0] + (slide_up(c) ? c->slide_shift : 0); }
+// layers [zl_begin, zl_begin + nlayers) in sweep order, slide_chunk layers per launch
+static int slide_layers(lbm_ctx* c, int zl_begin, int nlayers, int want_moments, float* msg_bottom = nullptr,
+                        float* msg_top = nullptr) {
+    if (nlayers <= 0) return LBM_OK;
+    const int K = c->slide_chunk;
+    const bool up = slide_up(c);
+    const int nchunks = (nlayers + K - 1) / K;
     for (int i = 0; i < nchunks; i++) {
         const int j = up ? nchunks - 1 - i : i;
-        const int nl = D - j * K < K ? D - j * K : K;
-        int rc = launch_stream_collide<3>(c, fin, fout, c->p, 1 + j * K, nl, 0, nullptr, nullptr, want_moments);
+        const int nl = nlayers - j * K < K ? nlayers - j * K : K;
+        int rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, zl_begin + j * K, nl, 0, msg_bottom, msg_top, want_moments);
         if (rc) return rc;
     }
-    c->slide_off = up ? c->slide_shift : 0;
-    c->ob_cur ^= 1;
     return LBM_OK;
+}
+static void slide_flip(lbm_ctx* c) {
+    c->slide_off = slide_up(c) ? c->slide_shift : 0;
+    c->ob_cur ^= 1;
+}
+static int slide_step(lbm_ctx* c, int want_moments) {
+    int rc = slide_layers(c, 1, c->g.D, want_moments);
+    if (!rc) slide_flip(c);
+    return rc;
+}
+// where the halo calls find the lattice: between lbm_step_interior_layers and lbm_step_finish the new
+// state already sits at the other position
+static inline float* halo_lattice(lbm_ctx* c) {
+    if (c->scheme == LBM_SCHEME_SLIDE) return c->split_phase ? slide_out(c) : c->f[0] + c->slide_off;
+    return c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
 }
 
 // bring rho/u up to date: what the reference's per-step writes would hold right now
@@ -373,8 +398,6 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown preset %d", o.preset);
     if (o.scheme != LBM_SCHEME_AB && o.scheme != LBM_SCHEME_AA && o.scheme != LBM_SCHEME_SLIDE)
         return fail(nullptr, LBM_ERR_INVALID, "lbm_create: unknown scheme %d", o.scheme);
-    if (o.scheme == LBM_SCHEME_SLIDE && o.depth_global > 0)
-        return fail(nullptr, LBM_ERR_INVALID, "lbm_create: the sliding in-place scheme does not run as z-slabs (use LBM_SCHEME_AB or LBM_SCHEME_AA)");
     int Dg = o.depth_global > 0 ? o.depth_global : depth;
     int z0 = o.depth_global > 0 ? o.z0 : 0;
     if (z0 < 0 || (long long)z0 + depth > Dg)
@@ -499,9 +522,11 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         CR(hipMemsetAsync(c->prev_mask, 0, mask_bytes, c->stream));
     } else if (slide) {
         CR(hipMalloc(&c->f[0], c->pop_bytes));
-        const size_t ob_bytes = (size_t)OB_N * (depth + 2) * height * sizeof(float);
-        CR(hipMalloc(&c->ob[0], ob_bytes));
-        CR(hipMalloc(&c->ob[1], ob_bytes));
+        if (!g.slab) {  // a slab reads the wrapped outlet column from its ghost layers like A/B
+            const size_t ob_bytes = (size_t)OB_N * (depth + 2) * height * sizeof(float);
+            CR(hipMalloc(&c->ob[0], ob_bytes));
+            CR(hipMalloc(&c->ob[1], ob_bytes));
+        }
     } else if (const char* t = getenv("LBM_AB_SINGLE")) {  // probe: both buffers in one allocation, a chosen distance apart
         const long long skew = std::max(0ll, atoll(t)) / 128 * 32;
         CR(hipMalloc(&c->alloc0, 2 * c->pop_bytes + (size_t)skew * sizeof(float)));
@@ -548,9 +573,11 @@ int lbm_init(lbm_ctx* c) {
                        c->f[1] ? c->f[1] : c->f[0], c->g, c->layout == LBM_LAYOUT_ROWS ? 1 : 0, first, last);
     HIPCHK(c, hipGetLastError());
     if (c->scheme != LBM_SCHEME_AB) {
-        const long long per = (long long)(c->g.D + 2) * c->g.H;
-        hipLaunchKernelGGL(k_ob_fill, grid1(per * OB_N), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
-        HIPCHK(c, hipGetLastError());
+        if (c->ob[0]) {
+            const long long per = (long long)(c->g.D + 2) * c->g.H;
+            hipLaunchKernelGGL(k_ob_fill, grid1(per * OB_N), dim3(256), 0, c->stream, c->ob[0], c->ob[1], per);
+            HIPCHK(c, hipGetLastError());
+        }
         c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
         c->slide_off = 0;
     }
@@ -935,9 +962,11 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     rc = copy_populations(c, const_cast<float*>(f), false);
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_SLIDE) {  // the outlet column's side array follows the new populations
-        hipLaunchKernelGGL(k_ob_gather, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
-                           current_populations(c), c->ob[0], c->ob[1], c->g);
-        HIPCHK(c, hipGetLastError());
+        if (c->ob[0]) {
+            hipLaunchKernelGGL(k_ob_gather, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
+                               current_populations(c), c->ob[0], c->ob[1], c->g);
+            HIPCHK(c, hipGetLastError());
+        }
         return LBM_OK;
     }
     c->mask_dirty = true;  // solid cells of the other buffer must follow
@@ -1055,7 +1084,6 @@ int lbm_halo_message_floats(lbm_ctx* c, size_t* nfloats) {
 
 static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
     if (!c->g.slab) return fail(c, LBM_ERR_STATE, "%s: context was not created as a slab (lbm_opts.depth_global = 0)", who);
-    if (c->scheme == LBM_SCHEME_SLIDE) return fail(c, LBM_ERR_STATE, "%s: the sliding in-place scheme does not run as z-slabs", who);
     if (side != 0 && side != 1) return fail(c, LBM_ERR_INVALID, "%s: side must be 0 or 1", who);
     if (!p) return fail(c, LBM_ERR_INVALID, "%s: buffer is null", who);
     return LBM_OK;
@@ -1068,7 +1096,7 @@ int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
     if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, d_message, true);
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     // after lbm_step_interior_layers the new state is still f[1-cur] until lbm_step_finish
-    const float* src = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    const float* src = halo_lattice(c);
     hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, src, d_message, c->g, side);
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
@@ -1079,8 +1107,10 @@ int lbm_halo_unpack(lbm_ctx* c, int side, const float* d_message) {
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_unpack");
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, const_cast<float*>(d_message), false);
+    if (c->scheme == LBM_SCHEME_SLIDE && c->split_phase == 1)
+        return fail(c, LBM_ERR_STATE, "lbm_halo_unpack: sliding scheme: the ghost layers of the new lattice position are free only after lbm_step_interior_layers");
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
-    float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    float* dst = halo_lattice(c);
     hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, dst, d_message, c->g, side);
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
@@ -1128,7 +1158,6 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
 int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
     NEED(c);
     if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
-    if (c->scheme == LBM_SCHEME_SLIDE) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: the sliding in-place scheme has no split step");
     if ((d_msg_bottom || d_msg_top) && !c->g.slab)
         return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: messages need a slab context");
     const bool was_dirty = c->mask_dirty;
@@ -1150,6 +1179,20 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
         if (!rc && d_msg_top) rc = aa_halo(c, 1, d_msg_top, true, bs);
         return rc;
     }
+    if (c->scheme == LBM_SCHEME_SLIDE) {
+        // the boundary layer the sweep starts with: real update + message; the other one: message only
+        hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
+        rc = ensure_field_buffers(c);
+        if (rc) return rc;
+        const int D = c->g.D, want = c->g.fnz > 0;
+        const int first = slide_up(c) ? D : 1, last = slide_up(c) ? 1 : D;
+        rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, first, 1, 0, d_msg_bottom, d_msg_top, want, bs);
+        if (!rc && D > 1)
+            rc = launch_stream_collide<3>(c, slide_in(c), nullptr, c->p, last, 1, 0, d_msg_bottom, d_msg_top, 0, bs);
+        if (rc) return rc;
+        c->split_phase = 1;
+        return LBM_OK;
+    }
     // one launch for both boundary layers; it writes the outgoing messages as it goes
     rc = launch_stream_collide<2>(c, c->f[c->cur], c->f[1 - c->cur], c->p, 1, c->g.D > 1 ? 2 : 1, c->g.D,
                                   d_msg_bottom, d_msg_top);
@@ -1168,8 +1211,10 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
         if (!rc && d_from_above) rc = aa_halo(c, 1, const_cast<float*>(d_from_above), false);
         return rc;
     }
+    if (c->scheme == LBM_SCHEME_SLIDE && c->split_phase == 1)
+        return fail(c, LBM_ERR_STATE, "lbm_halo_unpack_both: sliding scheme: the ghost layers of the new lattice position are free only after lbm_step_interior_layers");
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
-    float* dst = c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
+    float* dst = halo_lattice(c);
     hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, c->stream, dst, d_from_below, d_from_above, c->g);
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
@@ -1178,8 +1223,16 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
 int lbm_step_interior_layers(lbm_ctx* c) {
     NEED(c);
     if (c->split_phase != 1) return fail(c, LBM_ERR_STATE, "lbm_step_interior_layers: call lbm_step_boundary_layers first");
-    int rc = c->scheme == LBM_SCHEME_AA ? launch_aa_layers(c, c->g.fnz > 0, 2, c->g.D - 2)
+    int rc;
+    if (c->scheme == LBM_SCHEME_SLIDE) {
+        const int D = c->g.D, want = c->g.fnz > 0;
+        rc = slide_layers(c, 2, D - 2, want);
+        // the boundary layer the sweep ends with (its message left in lbm_step_boundary_layers)
+        if (!rc && D > 1) rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, slide_up(c) ? 1 : D, 1, 0, nullptr, nullptr, want);
+    } else {
+        rc = c->scheme == LBM_SCHEME_AA ? launch_aa_layers(c, c->g.fnz > 0, 2, c->g.D - 2)
                                         : launch_ab_layers(c, 2, c->g.D - 2);
+    }
     if (rc) return rc;
     c->split_phase = 2;
     return LBM_OK;
@@ -1189,10 +1242,11 @@ int lbm_step_finish(lbm_ctx* c) {
     NEED(c);
     if (c->split_phase != 2) return fail(c, LBM_ERR_STATE, "lbm_step_finish: call lbm_step_interior_layers first");
     if (c->scheme == LBM_SCHEME_AA) aa_flip(c);
+    else if (c->scheme == LBM_SCHEME_SLIDE) slide_flip(c);
     else c->cur = 1 - c->cur;
     c->p_last = c->p;
     c->steps += 1;
-    c->fields = c->scheme == LBM_SCHEME_AA ? FIELDS_VALID : FIELDS_STALE;
+    c->fields = c->scheme == LBM_SCHEME_AB ? FIELDS_STALE : FIELDS_VALID;
     c->curl_valid = false;
     c->split_phase = 0;
     return LBM_OK;

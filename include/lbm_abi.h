@@ -62,7 +62,9 @@ enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
  * shift, so a launch never overwrites what it or a later launch still reads.  Same results, the
  * A/B kernel's aligned access pattern, 1/2 + (chunk + 2)/(2 D) of the memory; a solid cell's frozen
  * populations move with the lattice, so every result equals A/B's, solid cells included; rho/u are
- * written by the last step of each lbm_step() call as in AA; it does not run as z-slabs. */
+ * written by the last step of each lbm_step() call as in AA.  It runs as z-slabs with the same calls
+ * and the A/B message format; lbm_halo_unpack / lbm_halo_unpack_both must then come AFTER
+ * lbm_step_interior_layers (the ghost layers of the new lattice position are input until then). */
 enum { LBM_SCHEME_AB = 0, LBM_SCHEME_AA = 1, LBM_SCHEME_SLIDE = 2 };
 
 /* Population storage in HBM (fp32 SoA rows padded to 128-byte lines either way):

@@ -77,7 +77,7 @@ static void ResetAndStep(const char* cube_obj) {
 }
 
 // cuda_buffer surface on the solid mask (copy_from_host, memset) and the in-place scheme behind
-// the same class: AA must give the A/B fields bit for bit.
+// the same class: AA and the sliding scheme must give the A/B fields bit for bit.
 static void MaskWritesAndSchemes() {
     const int W = 96, H = 32, D = 24;
     const size_t n = static_cast<size_t>(W) * H * D;
@@ -85,9 +85,9 @@ static void MaskWritesAndSchemes() {
     for (int z = 8; z < 16; z++)
         for (int y = 0; y < 12; y++)
             for (int x = 30; x < 40; x++) mask[(static_cast<size_t>(z) * H + y) * W + x] = 255;
-    std::vector<float> rho[2];
-    for (int scheme = 0; scheme < 2; scheme++) {
-        lbm_solver solver(W, H, D, LBM_PRESET_WIND_TUNNEL_REF, scheme ? LBM_SCHEME_AA : LBM_SCHEME_AB);
+    std::vector<float> rho[3];
+    for (int scheme = 0; scheme < 3; scheme++) {
+        lbm_solver solver(W, H, D, LBM_PRESET_WIND_TUNNEL_REF, scheme);  // LBM_SCHEME_AB, _AA, _SLIDE
         solver.init();
         solver.add_solid({1, 1, 1, 4, 4, 4});
         solver.get_solid_mask().memset(0);                       // lbm_solver.cu:415
@@ -100,6 +100,7 @@ static void MaskWritesAndSchemes() {
         solver.get_density().copy_to_host(rho[scheme].data(), n);
     }
     EXPECT(rho[0] == rho[1]);
+    EXPECT(rho[0] == rho[2]);
 }
 
 int main(int argc, char** argv) {

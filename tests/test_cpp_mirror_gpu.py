@@ -30,7 +30,7 @@ def test_headless_driver_known_answer(tmp_path):
     assert os.path.getsize(prefix + ".solid.raw") == 64 ** 3
 
 
-@pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--preset", "cavity"], ["--autotune", "--steps", "120"]])
+@pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--scheme", "slide"], ["--preset", "cavity"], ["--autotune", "--steps", "120"]])
 def test_native_rccl_slab_driver(extra):
     """tools/lbm_slab_rccl.cpp: C++ host, RCCL ncclSend/ncclRecv between the slabs of one process.
     On this one-GPU box the wind-tunnel ring sends to itself through RCCL; --check compares with the

@@ -36,7 +36,7 @@ def run_slabs(lbm, W, H, Dg, preset, splits, mask, steps, params=None, scheme=0)
     return rho, u, f, cls
 
 
-@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
 @pytest.mark.parametrize("preset", [0, 1])
 @pytest.mark.parametrize("splits", [(32,), (16, 16), (11, 10, 11), (1, 30, 1), (2, 2, 28)])
 def test_slabs_equal_single_domain(oracle, lbm, preset, splits, scheme):
@@ -52,10 +52,12 @@ def test_slabs_equal_single_domain(oracle, lbm, preset, splits, scheme):
     np.testing.assert_array_equal(u, o.velocity())
     fluid = mask == 0
     np.testing.assert_array_equal(f[:, fluid], o.populations()[:, fluid])
+    if scheme == 2:   # the sliding scheme carries the solid cells' frozen populations along
+        np.testing.assert_array_equal(f, o.populations())
     np.testing.assert_array_equal(cls, o.classification()[0])
 
 
-@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
 def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm, scheme):
     """No mesh: the outlet quirk rows at y=0 / y=H-1 and the z wrap between the first and the
     last layer cross slab interfaces and the ring link."""
@@ -71,7 +73,7 @@ def test_slabs_empty_tunnel_outlet_wrap(oracle, lbm, scheme):
 
 
 @pytest.mark.parametrize("chunk", [0, 5])
-@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
 def test_slabs_cube_64(oracle, lbm, scheme, chunk, monkeypatch):
     """chunk 5: the interior update of every slab in launches of 5 layers (lbm_hip.hip auto_chunk)"""
     monkeypatch.setenv("LBM_AB_CHUNK", str(chunk))

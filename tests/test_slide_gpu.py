@@ -137,6 +137,26 @@ def test_slide_equals_ab_and_memory(lbm):
     assert b.stats()["population_bytes"] < 0.6 * a.stats()["population_bytes"]   # (64 + 2 + 10) / (2 * 66) layers
 
 
-def test_slide_rejects_slabs(lbm):
-    with pytest.raises(lbm.LbmError):
-        lbm.Solver(32, 8, 4, scheme=lbm.SCHEME_SLIDE, z0=0, depth_global=8)
+@pytest.mark.parametrize("chunk", [1, 2, 5])
+@pytest.mark.parametrize("splits", [(7, 9), (1, 14, 1), (2, 3, 11), (16,)])
+def test_slide_slabs_chunks(oracle, lbm, splits, chunk):
+    """z-slabs of the sliding scheme (the boundary layer the sweep reaches last sends its message from
+    a message-only pass): odd and even step counts, slabs of one and two layers, small chunks"""
+    from test_slab_gpu import run_slabs
+    W, H, Dg = 72, 10, 16
+    for preset in (0, 1):
+        o = oracle.Solver(W, H, Dg, preset)
+        o.init()
+        o.add_solid(20, 0, 2, 9, 6, 13)
+        o.add_solid(W - 2, 3, 6, 2, 4, 5)          # solid cells in the outlet column across interfaces
+        mask = o.solid_mask()
+        o.step(7)
+        import os
+        os.environ["LBM_SLIDE_CHUNK"] = str(chunk)
+        try:
+            rho, u, f, _ = run_slabs(lbm, W, H, Dg, preset, splits, mask, 7, scheme=lbm.SCHEME_SLIDE)
+        finally:
+            del os.environ["LBM_SLIDE_CHUNK"]
+        np.testing.assert_array_equal(rho, o.density(), err_msg=f"preset {preset}")
+        np.testing.assert_array_equal(u, o.velocity(), err_msg=f"preset {preset}")
+        np.testing.assert_array_equal(f, o.populations(), err_msg=f"preset {preset}")

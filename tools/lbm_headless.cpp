@@ -1,7 +1,7 @@
 // lbm_headless -- command-line caller of lbm_solver: what Engine/src/main.cpp's `cfd` layer does
 // (construct 400x100x100, init, load_mesh, step per frame; main.cpp:11-39) without the window.
 //   lbm_headless [--dims W H D] [--steps N] [--obj PATH] [--preset wind|cavity]
-//                [--scheme ab|aa] [--u U] [--omega-shear S] [--omega-bulk B] [--dump PREFIX]
+//                [--scheme ab|aa|slide] [--u U] [--omega-shear S] [--omega-bulk B] [--dump PREFIX]
 // Prints MLUPS and field statistics; --dump writes PREFIX.{rho,u,solid,curl}.raw in the reference
 // wire formats (idx = z*W*H + y*W + x) and PREFIX.json with the dimensions.
 #include <chrono>
@@ -33,11 +33,11 @@ int main(int argc, char** argv) {
         else if (is("--obj") && i + 1 < argc) obj = argv[++i];
         else if (is("--dump") && i + 1 < argc) prefix = argv[++i];
         else if (is("--preset") && i + 1 < argc) preset = !std::strcmp(argv[++i], "cavity") ? LBM_PRESET_CAVITY : LBM_PRESET_WIND_TUNNEL_REF;
-        else if (is("--scheme") && i + 1 < argc) scheme = !std::strcmp(argv[++i], "aa") ? LBM_SCHEME_AA : LBM_SCHEME_AB;
+        else if (is("--scheme") && i + 1 < argc) { ++i; scheme = !std::strcmp(argv[i], "aa") ? LBM_SCHEME_AA : (!std::strcmp(argv[i], "slide") ? LBM_SCHEME_SLIDE : LBM_SCHEME_AB); }
         else if (is("--u") && i + 1 < argc) s.inlet_velocity = (float)atof(argv[++i]);
         else if (is("--omega-shear") && i + 1 < argc) s.omega_shear = (float)atof(argv[++i]);
         else if (is("--omega-bulk") && i + 1 < argc) s.omega_bulk = (float)atof(argv[++i]);
-        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa] [--u U] [--omega-shear S] [--omega-bulk B] [--dump PREFIX]\n", argv[0]); return 2; }
+        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--u U] [--omega-shear S] [--omega-bulk B] [--dump PREFIX]\n", argv[0]); return 2; }
     }
     lbm_solver solver(W, H, D, preset, scheme);
     solver.get_settings() = s;

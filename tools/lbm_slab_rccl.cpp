@@ -4,7 +4,7 @@
 // the C++ twin of cfd_amd/slab.py, which drives the same ABI from one process per GPU.
 //
 //   lbm_slab_rccl [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity]
-//                 [--scheme ab|aa] [--autotune] [--check]
+//                 [--scheme ab|aa|slide] [--autotune] [--check]
 //
 // Per step and slab (two streams):
 //   side stream : lbm_step_boundary_layers (writes both outgoing messages) -> ncclSend/ncclRecv
@@ -75,10 +75,10 @@ int main(int argc, char** argv) {
         else if (is("--steps") && i + 1 < argc) steps = atoi(argv[++i]);
         else if (is("--obj") && i + 1 < argc) obj = argv[++i];
         else if (is("--preset") && i + 1 < argc) preset = !std::strcmp(argv[++i], "cavity") ? LBM_PRESET_CAVITY : LBM_PRESET_WIND_TUNNEL_REF;
-        else if (is("--scheme") && i + 1 < argc) scheme = !std::strcmp(argv[++i], "aa") ? LBM_SCHEME_AA : LBM_SCHEME_AB;
+        else if (is("--scheme") && i + 1 < argc) { ++i; scheme = !std::strcmp(argv[i], "aa") ? LBM_SCHEME_AA : (!std::strcmp(argv[i], "slide") ? LBM_SCHEME_SLIDE : LBM_SCHEME_AB); }
         else if (is("--check")) check = true;
         else if (is("--autotune")) autotune = true;
-        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa] [--autotune] [--check]\n", argv[0]); return 2; }
+        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--autotune] [--check]\n", argv[0]); return 2; }
     }
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
         o.struct_size = sizeof o; o.device = r; o.preset = preset; o.scheme = scheme;
         o.z0 = s.z0; o.depth_global = D; o.stream = s.main; o.boundary_stream = s.side; o.plane_skew_bytes = -1;
         LBM_OKAY(nullptr, lbm_create(&s.ctx, W, H, s.depth, &o));
-        if (scheme == LBM_SCHEME_AA && !check) LBM_OKAY(s.ctx, lbm_set_field_window(s.ctx, 0, 0));  // no per-step rho/u
+        if (scheme != LBM_SCHEME_AB && !check) LBM_OKAY(s.ctx, lbm_set_field_window(s.ctx, 0, 0));  // no per-step rho/u
         LBM_OKAY(s.ctx, lbm_halo_message_floats(s.ctx, &nfloats));
         for (int k = 0; k < 2; k++) {
             HIP_OK(hipMalloc(&s.send[k], nfloats * sizeof(float)));
@@ -219,7 +219,7 @@ int main(int argc, char** argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double cells = (double)W * H * D;
     std::printf("%dx%dx%d in %d z-slabs over RCCL (%s, %s): %d steps, %.3f ms/step, %.1f MLUPS\n", W, H, D, P,
-                ring ? "wind tunnel, ring" : "cavity, chain", scheme == LBM_SCHEME_AA ? "AA" : "A/B", steps + tuned,
+                ring ? "wind tunnel, ring" : "cavity, chain", scheme == LBM_SCHEME_AA ? "AA" : (scheme == LBM_SCHEME_SLIDE ? "sliding A/B" : "A/B"), steps + tuned,
                 dt / (steps - warm) * 1e3, cells * (steps - warm) / dt / 1e6);
 
     int bad = 0;
