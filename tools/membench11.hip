@@ -1,0 +1,58 @@
+// membench11.hip -- does the bare 19-in / 19-out row-interleaved stream depend on the launch length?
+// Copy and pull pattern (no arithmetic) over 256 x 256 x D cells, D = 256 and 1024, in one launch and
+// in launches of K layers.  Buffers padded by one ghost row / layer on every side.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <initializer_list>
+constexpr int W = 256, H = 256, HP = H + 2;
+__constant__ int CX[19] = {0, 1, -1, 0, 0, 0, 0, 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0};
+__constant__ int CY[19] = {0, 0, 0, 1, -1, 0, 0, 1, -1, -1, 1, 0, 0, 0, 0, 1, -1, 1, -1};
+__constant__ int CZ[19] = {0, 0, 0, 0, 0, 1, -1, 0, 0, 0, 0, 1, -1, -1, 1, 1, -1, -1, 1};
+
+template <int PULL> __global__ __launch_bounds__(256) void k_ri(const float* __restrict__ in, float* __restrict__ out, int z0) {
+    const int x = threadIdx.x, y = blockIdx.x + 1, z = z0 + (int)blockIdx.y + 1;
+    const long long own = ((long long)z * HP + y) * (19 * W) + x;
+    float v[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+        long long a = own + k * W;
+        if (PULL) a = ((long long)(z - CZ[k]) * HP + (y - CY[k])) * (19 * W) + k * W + (x - CX[k]);
+        v[k] = __builtin_nontemporal_load(in + a);
+    }
+#pragma unroll
+    for (int k = 0; k < 19; k++) __builtin_nontemporal_store(v[k] * 1.0001f, out + own + k * W);
+}
+
+int main() {
+    for (int D : {256, 1024}) {
+        const long long total = (long long)(D + 2) * HP * 19 * W + 4096;  // floats; every shifted read stays inside
+        float *A, *B;
+        if (hipMalloc(&A, total * 4) != hipSuccess || hipMalloc(&B, total * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+        (void)hipMemset(A, 0, total * 4); (void)hipMemset(B, 0, total * 4);
+        const double bytes = 38.0 * W * H * D * 4;
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int pull = 0; pull < 2; pull++)
+            for (int K : {0, 512, 256, 128, 96, 64, 32, 16}) {
+                if (K >= D) continue;
+                const int chunk = K ? K : D;
+                auto step = [&](const float* in, float* out) {
+                    for (int z0 = 0; z0 < D; z0 += chunk) {
+                        const int nl = D - z0 < chunk ? D - z0 : chunk;
+                        if (pull) k_ri<1><<<dim3(H, nl), 256>>>(in, out, z0); else k_ri<0><<<dim3(H, nl), 256>>>(in, out, z0);
+                    }
+                };
+                step(A, B); step(B, A); (void)hipDeviceSynchronize();
+                float best = 1e9;
+                for (int r = 0; r < 3; r++) {
+                    (void)hipEventRecord(e0);
+                    for (int i = 0; i < 4; i++) { step(A, B); step(B, A); }
+                    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 8; best = ms < best ? ms : best;
+                }
+                printf("256x256x%-4d %s layers/launch %-4d : %8.1f us %6.3f TB/s\n", D, pull ? "pull" : "copy", chunk, best * 1e3, bytes / (best * 1e-3) / 1e12);
+                fflush(stdout);
+            }
+        (void)hipFree(A); (void)hipFree(B);
+    }
+    return 0;
+}
