@@ -162,6 +162,8 @@ static int refresh_mask_state(lbm_ctx* c) {
     else
         hipLaunchKernelGGL(k_tile_flags<LBM_PRESET_WIND_TUNNEL_REF>, grid1(ntiles), dim3(256), 0, c->stream, c->mask, c->flags, c->g);
     HIPCHK(c, hipGetLastError());
+    if (getenv("LBM_FORCE_GENERAL"))  // probe: every tile takes the boundary path (same results, measures its cost)
+        HIPCHK(c, hipMemsetAsync(c->flags, 1, (size_t)ntiles, c->stream));
     if (c->scheme == LBM_SCHEME_AA) {
         hipLaunchKernelGGL(k_aa_refluidize, grid1(cells(c)), dim3(256), 0, c->stream, c->f[0],
                            c->ob[c->ob_cur], c->prev_mask, c->mask, c->g, c->aa_phase);
