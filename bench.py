@@ -13,8 +13,8 @@ send/recv (torch.distributed backend "nccl"), overlapped with the interior updat
 --config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised
 car stand-in (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
 --config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
---config 4: configs[4], in-place scheme sized to HBM (~3.4 G cells per GPU): the sliding A/B scheme on one
-GPU, AA (the in-place scheme that runs as z-slabs) for weak scaling over N > 1.
+--config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), weak scaling over z-slabs;
+`--config 4 --scheme slide` runs the same domain on the sliding in-place A/B scheme (8 % faster).
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the solver's stream;
 `cpu_baseline` times the CPU oracle (a port of the reference update: the reference has no CPU path)
 on a bounded sample of the same workload, on rank 0 at N = 1 only.
@@ -109,7 +109,7 @@ def main():
     cfg = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
            2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
            3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
-           4: ((1504, 1536, 1484), "wind_tunnel", "slide", None, "weak")}[args.config]
+           4: ((1504, 1536, 1484), "wind_tunnel", "aa", None, "weak")}[args.config]
     size, preset_name, scheme_name, obstacle, scaling = cfg
     if args.size:
         size = tuple(args.size)

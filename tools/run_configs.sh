@@ -15,4 +15,4 @@ run 400 --config 3 --steps 30 --warmup 5
 run 400 --config 3 --steps 30 --warmup 5 --scheme aa --no-cpu-baseline
 run 400 --config 3 --steps 30 --warmup 5 --scheme slide --no-cpu-baseline
 run 600 --config 4 --steps 20 --warmup 3
-run 600 --config 4 --steps 20 --warmup 3 --scheme aa --no-cpu-baseline
+run 600 --config 4 --steps 20 --warmup 3 --scheme slide --no-cpu-baseline
