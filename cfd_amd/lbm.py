@@ -20,6 +20,8 @@ LAYOUT_DEFAULT = 0
 LAYOUT_PLANES = 1
 LAYOUT_ROWS = 2
 
+ABI_VERSION = 1   # include/lbm_abi.h LBM_ABI_VERSION
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
 
@@ -115,6 +117,9 @@ def load_library(path=None):
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = res
+        if lib.lbm_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{p}: ABI version {lib.lbm_abi_version()}, this binding is written for {ABI_VERSION} "
+                               "(rebuild with `make -C cfd_amd/csrc`)")
         _lib = lib
     return _lib
 
