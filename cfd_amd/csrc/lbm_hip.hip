@@ -361,6 +361,24 @@ static int materialise_fields(lbm_ctx* c) {
     return LBM_OK;
 }
 
+// Waves a workgroup puts side by side in x (1, 2 or 4; the rest of its 4 waves stack in y).  Wide
+// workgroups stream best when the row divides evenly (256^3: 6.16 TB/s with 4, 5.81 with 2, 5.45 with
+// 1), but a row of Wt 64-cell segments is padded to a multiple of that width with waves that exit at
+// once: the reference's default 400x100x100 domain (Wt = 7) runs at 5.15 / 5.30 / 5.8 TB/s with 4 / 2 /
+// 1.  Pick the width with the least padded waves, weighted by those measured rates.
+static int pick_segsx_log2(int Wt) {
+    const double penalty[3] = {1.12, 1.06, 1.0};
+    int best = 0;
+    double best_cost = 1e30;
+    for (int l = 0; l < 3; l++) {
+        const int segsx = 1 << l;
+        if (l > 0 && segsx > Wt) break;
+        const double cost = (double)((Wt + segsx - 1) / segsx * segsx) * penalty[l];
+        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && l > best)) { best_cost = cost; best = l; }
+    }
+    return best;
+}
+
 // Layers per launch.  Measured on MI355X (profiles/r01_tuning.md, "layers per launch"): a step cut into
 // launches of about 1 GB of algorithmic traffic runs 2-4 % faster than one launch over the whole
 // domain (256^3: 6.09 -> 6.27 TB/s at 96 layers, 512x256x256: 5.75 -> 5.98 at 32-64, 1024x512x512:
@@ -441,7 +459,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         if (o.slide_chunk < 0) { delete c; return fail(nullptr, LBM_ERR_INVALID, "lbm_create: slide_chunk %d", o.slide_chunk); }
         // default: the measured-best launch size, but at most a quarter of the depth in spare layers
         // (the scheme exists to save memory); slide_chunk / LBM_SLIDE_CHUNK override
-        c->slide_chunk = std::max(2, std::min(auto_chunk(g, g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0)), depth / 4));
+        c->slide_chunk = std::max(2, std::min(auto_chunk(g, pick_segsx_log2(g.Wt)), depth / 4));
         if (o.slide_chunk > 0) c->slide_chunk = o.slide_chunk;
         if (const char* t = getenv("LBM_SLIDE_CHUNK")) c->slide_chunk = std::max(1, atoi(t));
         if (c->slide_chunk > depth) c->slide_chunk = depth;
@@ -469,8 +487,8 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     }
     c->guard_floats = guard;
     c->slide_shift = (long long)(c->slide_chunk + 2) * g.layer + c->slide_skew;
-    c->segsx_log2 = g.Wt >= 4 ? 2 : (g.Wt >= 2 ? 1 : 0);
-    if (const char* t = getenv("LBM_SEGSX")) c->segsx_log2 = std::min(c->segsx_log2, std::max(0, atoi(t)));
+    c->segsx_log2 = pick_segsx_log2(g.Wt);
+    if (const char* t = getenv("LBM_SEGSX")) c->segsx_log2 = std::min(2, std::max(0, atoi(t)));
     // measured on MI355X at 256^3 (profiles/r01_tuning.md): nt loads + sc1 (write-through) stores +
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
     // In place (AA) the write-through stores lose: partial-line neighbour writes no longer combine
