@@ -1,4 +1,5 @@
-"""Long-run agreement: the in-place AA kernel and a 4-slab A/B run against the plain A/B run after many steps
+"""Long-run agreement: the in-place AA kernel, a 4-slab A/B run, the sliding scheme and a 3-slab sliding run
+against the plain A/B run after many steps
 (bit for bit), on BASELINE.json configs[2] (512x256x256 wind tunnel + car stand-in).  One-off probe."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,4 +27,16 @@ for e in engines:
     e.solver.init(); e.solver.load_mesh(car)
 cl.exchange_mask(); cl.exchange_populations(); cl.step(steps)
 print("4 slabs identical to A/B:", same(np.concatenate([e.solver.density() for e in engines]), rho)
+      and same(np.concatenate([e.solver.velocity() for e in engines]), u), f"({time.time()-t0:.0f} s)", flush=True)
+for e in engines:
+    e.solver.close()
+c = lbm.Solver(W, H, D, scheme=lbm.SCHEME_SLIDE); c.init(); c.load_mesh(car); c.step(steps)
+print("sliding identical to A/B:", same(c.density(), rho) and same(c.velocity(), u), flush=True)
+c.close()
+engines = [slab.HipSlabEngine(W, H, D, z0, d, 0, scheme=lbm.SCHEME_SLIDE) for z0, d in ((0, 100), (100, 56), (156, 100))]
+cl = slab.LocalSlabCluster(engines, 0)
+for e in engines:
+    e.solver.init(); e.solver.load_mesh(car)
+cl.exchange_mask(); cl.exchange_populations(); cl.step(steps)
+print("3 sliding slabs identical to A/B:", same(np.concatenate([e.solver.density() for e in engines]), rho)
       and same(np.concatenate([e.solver.velocity() for e in engines]), u), f"({time.time()-t0:.0f} s)", flush=True)
