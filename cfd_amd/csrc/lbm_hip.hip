@@ -457,9 +457,11 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     const bool slide = o.scheme == LBM_SCHEME_SLIDE;
     if (slide) {
         if (o.slide_chunk < 0) { delete c; return fail(nullptr, LBM_ERR_INVALID, "lbm_create: slide_chunk %d", o.slide_chunk); }
-        // default: the measured-best launch size, but at most a quarter of the depth in spare layers
-        // (the scheme exists to save memory); slide_chunk / LBM_SLIDE_CHUNK override
-        c->slide_chunk = std::max(2, std::min(auto_chunk(g, pick_segsx_log2(g.Wt)), depth / 4));
+        // default: the measured-best launch size, but at most a quarter of the depth (or 256 MB, whichever
+        // is more) in spare layers -- the scheme exists to save memory; slide_chunk / LBM_SLIDE_CHUNK override
+        const long long layer_pop_bytes = (long long)Q * width * height * (long long)sizeof(float);
+        const int cap = (int)std::max<long long>(depth / 4, (256ll << 20) / layer_pop_bytes);
+        c->slide_chunk = std::max(2, std::min(auto_chunk(g, pick_segsx_log2(g.Wt)), cap));
         if (o.slide_chunk > 0) c->slide_chunk = o.slide_chunk;
         if (const char* t = getenv("LBM_SLIDE_CHUNK")) c->slide_chunk = std::max(1, atoi(t));
         if (c->slide_chunk > depth) c->slide_chunk = depth;
