@@ -160,3 +160,24 @@ def test_slide_slabs_chunks(oracle, lbm, splits, chunk):
         np.testing.assert_array_equal(rho, o.density(), err_msg=f"preset {preset}")
         np.testing.assert_array_equal(u, o.velocity(), err_msg=f"preset {preset}")
         np.testing.assert_array_equal(f, o.populations(), err_msg=f"preset {preset}")
+
+
+def test_slide_slab_unpack_order_enforced(lbm):
+    """the ghost layers of the new lattice position are input until the interior has run: the
+    library refuses an unpack between lbm_step_boundary_layers and lbm_step_interior_layers"""
+    from cfd_amd import slab
+    e = slab.HipSlabEngine(64, 8, 12, 0, 6, lbm.PRESET_WIND_TUNNEL, scheme=lbm.SCHEME_SLIDE)
+    e.solver.init()
+    send, recv = [e.new_message(), e.new_message()], [e.new_message(), e.new_message()]
+    for m in recv:
+        m.zero_()
+    e.step_boundary(send[0], send[1])
+    with pytest.raises(lbm.LbmError):
+        e.halo_unpack_both(recv[0], recv[1])
+    with pytest.raises(lbm.LbmError):
+        e.solver.step(1)                      # a split step is in flight
+    e.step_interior()
+    e.halo_unpack_both(recv[0], recv[1])
+    e.step_finish()
+    e.solver.step(1)
+    e.solver.close()
