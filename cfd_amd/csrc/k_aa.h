@@ -200,6 +200,21 @@ __global__ void k_aa_refluidize(float* M, float* __restrict__ ob_cur, const unsi
         for (int j = 0; j < OB_N; j++) ob_cur[ob_at(g, j, z, y)] = weight(OB_PLANE[j]);
 }
 
+// Sliding scheme, "pristine" mode (all solid cells hold w_k and are not carried along): write w_k into
+// the slots of the cells that `mask` marks solid, at the lattice position `f` -- before somebody reads
+// those slots (population read-back, halo pack) or before solid cells start to matter (mask change).
+__global__ void k_slide_fill_solids(float* __restrict__ f, const unsigned long long* __restrict__ mask, Geo g) {
+    const long long i = gidx();
+    const long long n = (long long)g.W * g.H * g.D;
+    if (i >= n) return;
+    const long long row = i / g.W;
+    const int x = (int)(i - row * g.W);
+    const int z = (int)(row / g.H);
+    const int y = (int)(row - (long long)z * g.H);
+    if (!solid_at(g, mask, x, y, z + 1)) return;
+    const long long own = cell_off(g, x, y, z + 1);
+    for (int k = 0; k < Q; k++) f[(long long)k * g.plane + own] = weight(k);
+}
 // outlet column of plainly addressed populations -> both side arrays (after lbm_write_populations)
 __global__ void k_ob_gather(const float* __restrict__ f, float* __restrict__ ob_a, float* __restrict__ ob_b, Geo g) {
     const long long col = gidx();

@@ -357,7 +357,14 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
     if (x >= g.W) return;
     if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
-    if (MODE == 3) want_moments = want_moments && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
+    // MODE 3, want_moments bit 1: every solid cell still holds the rest populations init() wrote
+    // (w_k), so they need not travel with the lattice: solid lanes neither load nor store (but for the
+    // outlet column, which a slab's outlet branch reads from the lattice) and all-solid tiles exit
+    const bool skip_solid = MODE == 3 && (want_moments & 2);
+    if (MODE == 3) want_moments = (want_moments & 1) && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
+    if (MODE == 3 && skip_solid && flag == 2 && !want_moments && t.xs != g.Wt - 1 &&
+        !((zl == 1 && msg_bottom) || (zl == g.D && msg_top)))
+        return;
 
     const long long own = cell_off(g, x, y, zl);
     const float inlet_e = inlet_bracket(p.U);
@@ -377,13 +384,13 @@ __global__ __launch_bounds__(256) void k_stream_collide(
             }
             if (MODE == 2 || MODE == 3) {
 #pragma unroll
-                for (int k = 0; k < Q; k++) f[k] = fin[(long long)k * g.plane + own];
+                for (int k = 0; k < Q; k++) f[k] = skip_solid ? weight(k) : fin[(long long)k * g.plane + own];
             }
             if (MODE == 2 || MODE == 3) {  // the neighbour's outlet branch may read a solid cell: send its frozen values
                 if (zl == 1 && msg_bottom) emit_halo(g, msg_bottom, 0, x, y, f);
                 if (zl == g.D && msg_top) emit_halo(g, msg_top, 1, x, y, f);
             }
-            if (MODE == 3 && fout) {  // the lattice moves: a solid cell's frozen populations move with it
+            if (MODE == 3 && fout && (!skip_solid || x == g.W - 1)) {  // the lattice moves: a solid cell's frozen populations move with it
 #pragma unroll
                 for (int k = 0; k < Q; k++) fout[(long long)k * g.plane + own] = f[k];
             }

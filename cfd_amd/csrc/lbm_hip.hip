@@ -84,6 +84,9 @@ struct lbm_ctx {
     int ab_chunk = 0;        // A/B: layers per launch (0 = the whole domain in one launch)
     long long slide_off = 0;   // SLIDE: offset (floats) of the lattice inside the buffer right now: 0 or slide_shift
     long long slide_shift = 0; // SLIDE: (chunk + 2) layers + slide_skew
+    bool slide_pristine = false;  // SLIDE: every solid cell holds w_k (init() wrote it, no fluid cell turned solid after a
+                                  // step): solid cells are skipped instead of carried along (k_stream_collide MODE 3)
+    bool slide_stepped = false;   // SLIDE: a step ran since init(): skipped solid cells' slots hold stale values
     long long slide_skew = 0;  // SLIDE: extra floats between the two positions (DRAM bank alignment of loads against stores)
     float* alloc0 = nullptr;   // AA: start of the allocation (f[0] sits behind a front guard)
     float* ob[2] = {nullptr, nullptr};
@@ -153,6 +156,8 @@ static int ensure_field_buffers(lbm_ctx* c) {
     return LBM_OK;
 }
 
+static int slide_fill_solids(lbm_ctx* c, const unsigned long long* mask);
+
 // rebuild tile flags and re-freeze solid cells after a mask / population change
 static int refresh_mask_state(lbm_ctx* c) {
     if (!c->mask_dirty) return LBM_OK;
@@ -173,8 +178,16 @@ static int refresh_mask_state(lbm_ctx* c) {
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->prev_mask, c->mask, c->mask_bytes, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->scheme == LBM_SCHEME_SLIDE) {
-        // solid cells are carried along by the step itself (k_stream_collide MODE 3); only the outlet
-        // column's side array needs the frozen values in both of its buffers
+        // A mask change after a step ends the pristine mode (cells that turn solid now freeze what they
+        // hold, no longer w_k): give the cells that were solid so far their w_k back first.  From here on
+        // solid cells are carried along by the step itself (k_stream_collide MODE 3).  The outlet
+        // column's side array needs the frozen values in both of its buffers.
+        if (c->slide_pristine && c->slide_stepped) {
+            int rc = slide_fill_solids(c, c->prev_mask);
+            if (rc) return rc;
+            c->slide_pristine = false;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->prev_mask, c->mask, c->mask_bytes, hipMemcpyDeviceToDevice, c->stream));
         if (c->ob[0]) {
             hipLaunchKernelGGL(k_ob_sync, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
                                c->ob[c->ob_cur], c->ob[1 - c->ob_cur], c->mask, c->g);
@@ -318,7 +331,8 @@ static int slide_layers(lbm_ctx* c, int zl_begin, int nlayers, int want_moments,
     for (int i = 0; i < nchunks; i++) {
         const int j = up ? nchunks - 1 - i : i;
         const int nl = nlayers - j * K < K ? nlayers - j * K : K;
-        int rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, zl_begin + j * K, nl, 0, msg_bottom, msg_top, want_moments);
+        int rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, zl_begin + j * K, nl, 0, msg_bottom, msg_top,
+                                          want_moments | (c->slide_pristine ? 2 : 0));
         if (rc) return rc;
     }
     return LBM_OK;
@@ -326,6 +340,14 @@ static int slide_layers(lbm_ctx* c, int zl_begin, int nlayers, int want_moments,
 static void slide_flip(lbm_ctx* c) {
     c->slide_off = slide_up(c) ? c->slide_shift : 0;
     c->ob_cur ^= 1;
+    c->slide_stepped = true;
+}
+// pristine mode: make the slots of the cells `mask` marks solid valid (w_k) at the current lattice position
+static int slide_fill_solids(lbm_ctx* c, const unsigned long long* mask) {
+    if (!(c->slide_pristine && c->slide_stepped)) return LBM_OK;
+    hipLaunchKernelGGL(k_slide_fill_solids, grid1(cells(c)), dim3(256), 0, c->stream, c->f[0] + c->slide_off, mask, c->g);
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
 }
 static int slide_step(lbm_ctx* c, int want_moments) {
     int rc = slide_layers(c, 1, c->g.D, want_moments);
@@ -544,6 +566,8 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
         CR(hipMemsetAsync(c->prev_mask, 0, mask_bytes, c->stream));
     } else if (slide) {
         CR(hipMalloc(&c->f[0], c->pop_bytes));
+        CR(hipMalloc(&c->prev_mask, mask_bytes));
+        CR(hipMemsetAsync(c->prev_mask, 0, mask_bytes, c->stream));
         if (!g.slab) {  // a slab reads the wrapped outlet column from its ghost layers like A/B
             const size_t ob_bytes = (size_t)OB_N * (depth + 2) * height * sizeof(float);
             CR(hipMalloc(&c->ob[0], ob_bytes));
@@ -602,6 +626,8 @@ int lbm_init(lbm_ctx* c) {
         }
         c->aa_phase = 0;  // w_k = w_inv(k): the equilibrium fill is valid in the streamed layout
         c->slide_off = 0;
+        c->slide_pristine = c->scheme == LBM_SCHEME_SLIDE;
+        c->slide_stepped = false;
     }
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
     c->curl_valid = false;
@@ -968,6 +994,10 @@ int lbm_read_populations(lbm_ctx* c, float* f, size_t n19) {
         int rc = refresh_mask_state(c);
         return rc ? rc : aa_copy_populations(c, f, true);
     }
+    if (c->scheme == LBM_SCHEME_SLIDE) {  // pristine mode: the solid cells' slots were not carried along
+        int rc = slide_fill_solids(c, c->prev_mask);
+        if (rc) return rc;
+    }
     return copy_populations(c, f, true);
 }
 
@@ -984,6 +1014,7 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     rc = copy_populations(c, const_cast<float*>(f), false);
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_SLIDE) {  // the outlet column's side array follows the new populations
+        c->slide_pristine = false;        // solid cells now hold what the caller wrote: carry them along
         if (c->ob[0]) {
             hipLaunchKernelGGL(k_ob_gather, grid1((long long)c->g.D * c->g.H), dim3(256), 0, c->stream,
                                current_populations(c), c->ob[0], c->ob[1], c->g);
@@ -1117,6 +1148,10 @@ int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, d_message, true);
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
+    if (c->scheme == LBM_SCHEME_SLIDE && c->split_phase == 0) {  // pristine mode: solid cells of the boundary layers
+        rc = slide_fill_solids(c, c->prev_mask);
+        if (rc) return rc;
+    }
     // after lbm_step_interior_layers the new state is still f[1-cur] until lbm_step_finish
     const float* src = halo_lattice(c);
     hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for(per, 256), 6), dim3(256), 0, c->stream, src, d_message, c->g, side);
@@ -1208,9 +1243,10 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
         if (rc) return rc;
         const int D = c->g.D, want = c->g.fnz > 0;
         const int first = slide_up(c) ? D : 1, last = slide_up(c) ? 1 : D;
-        rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, first, 1, 0, d_msg_bottom, d_msg_top, want, bs);
+        const int skip = c->slide_pristine ? 2 : 0;
+        rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, first, 1, 0, d_msg_bottom, d_msg_top, want | skip, bs);
         if (!rc && D > 1)
-            rc = launch_stream_collide<3>(c, slide_in(c), nullptr, c->p, last, 1, 0, d_msg_bottom, d_msg_top, 0, bs);
+            rc = launch_stream_collide<3>(c, slide_in(c), nullptr, c->p, last, 1, 0, d_msg_bottom, d_msg_top, skip, bs);
         if (rc) return rc;
         c->split_phase = 1;
         return LBM_OK;
@@ -1250,7 +1286,9 @@ int lbm_step_interior_layers(lbm_ctx* c) {
         const int D = c->g.D, want = c->g.fnz > 0;
         rc = slide_layers(c, 2, D - 2, want);
         // the boundary layer the sweep ends with (its message left in lbm_step_boundary_layers)
-        if (!rc && D > 1) rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, slide_up(c) ? 1 : D, 1, 0, nullptr, nullptr, want);
+        if (!rc && D > 1)
+            rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, slide_up(c) ? 1 : D, 1, 0, nullptr, nullptr,
+                                          want | (c->slide_pristine ? 2 : 0));
     } else {
         rc = c->scheme == LBM_SCHEME_AA ? launch_aa_layers(c, c->g.fnz > 0, 2, c->g.D - 2)
                                         : launch_ab_layers(c, 2, c->g.D - 2);

@@ -61,7 +61,8 @@ enum { LBM_PRESET_WIND_TUNNEL_REF = 0, LBM_PRESET_CAVITY = 1 };
  * layer offset and writes it at the other, a chunk of layers per launch, in the direction of the
  * shift, so a launch never overwrites what it or a later launch still reads.  Same results, the
  * A/B kernel's aligned access pattern, 1/2 + (chunk + 2)/(2 D) of the memory; a solid cell's frozen
- * populations move with the lattice, so every result equals A/B's, solid cells included; rho/u are
+ * populations move with the lattice (or, while every solid cell still holds what lbm_init() wrote, are
+ * not stored at all), so every result equals A/B's, solid cells included; rho/u are
  * written by the last step of each lbm_step() call as in AA.  It runs as z-slabs with the same calls
  * and the A/B message format; lbm_halo_unpack / lbm_halo_unpack_both must then come AFTER
  * lbm_step_interior_layers (the ghost layers of the new lattice position are input until then). */

@@ -181,3 +181,32 @@ def test_slide_slab_unpack_order_enforced(lbm):
     e.step_finish()
     e.solver.step(1)
     e.solver.close()
+
+
+def test_slide_pristine_solids(oracle, lbm):
+    """the engine's call order (init, mask, steps): all solid cells hold w_k, so the sliding scheme
+    skips them instead of carrying them along; read-backs, a later mask change (solid cells turning
+    fluid again, fluid cells turning solid), reset and population import must all still equal the
+    oracle, solid cells included"""
+    W, H, D = 200, 20, 24
+    o, g = pair(oracle, lbm, W, H, D, chunk=5)
+    o.init(); g.init()
+    for s in (o, g):
+        s.add_solid(30, 0, 4, 90, 12, 14)              # all-solid 64-cell tiles inside
+        s.add_solid(W - 70, 5, 10, 70, 6, 6)           # reaches the outlet column, fills the last tile of its rows
+    o.step(5); g.step(5)
+    same(o, g, "pristine, 5 steps")
+    o.step(4); g.step(4)
+    same(o, g, "pristine, 9 steps (after a read-back)")
+    o.load_mesh(CUBE_OBJ); g.load_mesh(CUBE_OBJ)       # the boxes turn fluid, the cube and the floor solid
+    o.step(6); g.step(6)
+    same(o, g, "after the mask change")
+    o.step(3); g.step(3)
+    same(o, g, "carried along from here on")
+    o.reset(); g.reset()                               # pristine again, mask kept
+    o.step(7); g.step(7)
+    same(o, g, "after reset")
+    f = o.populations()
+    g.set_populations(f)
+    o.step(2); g.step(2)
+    same(o, g, "after import")
