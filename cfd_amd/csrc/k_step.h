@@ -311,7 +311,9 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2, int zorder) {
 
 // ------------------------------------------------------------------------------------------
 // the hot kernel: fused pull-stream + boundary chain + collision (lbm_solver.cu:242-402)
-// MODE 0: step (writes f_out).  MODE 1: moments only (writes rho/u in the reference layout).
+// MODE 0: step (writes f_out; with want_moments also rho/u of the field window, fused: 20 B/cell
+//         instead of the 96 B/cell of a MODE 1 pass).  MODE 1: moments only (writes rho/u in the
+//         reference layout).
 // MODE 2: step of the one or two slab-boundary layers (blockIdx.z = 0 -> zl_begin, 1 -> zl_second)
 //         that also writes the outgoing halo messages, so no separate pack pass is needed.
 // MODE 3: step of the sliding in-place scheme (LBM_SCHEME_SLIDE): fin and fout are the SAME buffer
@@ -356,12 +358,12 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
     if (x >= g.W) return;
-    if (MODE == 0 && flag == 2) return;  // every cell of the tile is solid: nothing moves
     // MODE 3, want_moments bit 1: every solid cell still holds the rest populations init() wrote
     // (w_k), so they need not travel with the lattice: solid lanes neither load nor store (but for the
     // outlet column, which a slab's outlet branch reads from the lattice) and all-solid tiles exit
     const bool skip_solid = MODE == 3 && (want_moments & 2);
-    if (MODE == 3) want_moments = (want_moments & 1) && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
+    if (MODE == 0 || MODE == 3) want_moments = (want_moments & 1) && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
+    if (MODE == 0 && flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
     if (MODE == 3 && skip_solid && flag == 2 && !want_moments && t.xs != g.Wt - 1 &&
         !((zl == 1 && msg_bottom) || (zl == g.D && msg_top)))
         return;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
         if ((tm.w[1][1] >> t.lane) & 1ull) {
             // lbm_solver.cu:258-267: rho = 0, u = 0.  The reference also copies f_in -> f_out
             // here; we keep solid cells frozen in both buffers instead (k_sync_solid).
-            if (MODE == 1 || (MODE == 3 && want_moments)) {
+            if (MODE == 1 || ((MODE == 0 || MODE == 3) && want_moments)) {
                 const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
                 rho_out[ridx] = 0.0f;
                 u_out[ridx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     }
 
     const Moments m = moments_of(f);
-    if (MODE == 1 || (MODE == 3 && want_moments)) {
+    if (MODE == 1 || ((MODE == 0 || MODE == 3) && want_moments)) {
         const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
         rho_out[ridx] = m.rho;
         u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);

@@ -84,6 +84,7 @@ struct lbm_ctx {
     int ab_chunk = 0;        // A/B: layers per launch (0 = the whole domain in one launch)
     long long slide_off = 0;   // SLIDE: offset (floats) of the lattice inside the buffer right now: 0 or slide_shift
     long long slide_shift = 0; // SLIDE: (chunk + 2) layers + slide_skew
+    bool fields_wanted = false;   // A/B: the caller read rho/u since its last lbm_step() call (fuse them into the next one)
     bool slide_pristine = false;  // SLIDE: every solid cell holds w_k (init() wrote it, no fluid cell turned solid after a
                                   // step): solid cells are skipped instead of carried along (k_stream_collide MODE 3)
     bool slide_stepped = false;   // SLIDE: a step ran since init(): skipped solid cells' slots hold stale values
@@ -233,14 +234,15 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
 }
 
 // A/B update of layers [zl_begin, zl_begin + nlayers) in launches of ab_chunk layers (see auto_chunk())
-static int launch_ab_layers(lbm_ctx* c, int zl_begin, int nlayers) {
+static int launch_ab_layers(lbm_ctx* c, int zl_begin, int nlayers, int want_moments = 0) {
     if (c->probe) { const char* t = getenv("LBM_AB_CHUNK"); c->ab_chunk = t ? std::max(0, atoi(t)) : 0; }
     const int K = c->ab_chunk > 0 ? c->ab_chunk : nlayers;
     const int nchunks = (nlayers + K - 1) / K;
     const bool top_down = (c->tune & 4) && c->zrev;  // the launches follow the layer order inside a launch
     for (int i = 0; i < nchunks; i++) {
         const int zb = (top_down ? nchunks - 1 - i : i) * K;
-        int rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, zl_begin + zb, std::min(K, nlayers - zb));
+        int rc = launch_stream_collide<0>(c, c->f[c->cur], c->f[1 - c->cur], c->p, zl_begin + zb, std::min(K, nlayers - zb),
+                                          0, nullptr, nullptr, want_moments);
         if (rc) return rc;
     }
     return LBM_OK;
@@ -414,6 +416,12 @@ static int auto_chunk(const Geo& g, int segsx_log2) {
     if (k >= g.D) return g.D;
     const long long n = (g.D + k - 1) / k;
     return (int)((g.D + n - 1) / n);
+}
+
+// the caller asks for rho/u (read-back, curl, device pointers)
+static int fields_for_caller(lbm_ctx* c) {
+    c->fields_wanted = true;
+    return materialise_fields(c);
 }
 
 extern "C" {
@@ -782,15 +790,24 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         c->curl_valid = false;
         return LBM_OK;
     }
+    // rho/u are made on demand from the previous buffer (96 B/cell).  A caller that read them after its
+    // previous lbm_step() call will most likely do so again (the engine's renderer does, every frame):
+    // then the last step of this call writes them as it goes (20 B/cell).
+    const bool fuse = c->fields_wanted && c->g.fnz > 0;
+    if (fuse) {
+        rc = ensure_field_buffers(c);
+        if (rc) return rc;
+    }
     for (int s = 0; s < nsteps; s++) {
-        rc = launch_ab_layers(c, 1, c->g.D);
+        rc = launch_ab_layers(c, 1, c->g.D, fuse && s == nsteps - 1);
         if (rc) return rc;
         c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
         c->zrev ^= 1;
     }
     c->p_last = c->p;
     c->steps += (uint64_t)nsteps;
-    c->fields = FIELDS_STALE;
+    c->fields = fuse ? FIELDS_VALID : FIELDS_STALE;
+    c->fields_wanted = false;
     c->curl_valid = false;
     return LBM_OK;
 }
@@ -799,7 +816,7 @@ int lbm_compute_curl(lbm_ctx* c) {
     NEED(c);
     int rc = refresh_mask_state(c);
     if (rc) return rc;
-    rc = materialise_fields(c);
+    rc = fields_for_caller(c);
     if (rc) return rc;
     if (c->curl_valid) return LBM_OK;
     if (c->g.fnz != c->g.D)
@@ -857,7 +874,7 @@ int lbm_read_density(lbm_ctx* c, float* rho, size_t n) {
     NEED(c);
     if (!rho || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_density: need %lld floats", field_cells(c));
     int rc = refresh_mask_state(c);
-    if (!rc) rc = materialise_fields(c);
+    if (!rc) rc = fields_for_caller(c);
     if (rc) return rc;
     return read_back(c, rho, c->rho, n * sizeof(float));
 }
@@ -866,7 +883,7 @@ int lbm_read_velocity(lbm_ctx* c, float* u, size_t n) {
     NEED(c);
     if (!u || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity: need %lld x 4 floats", field_cells(c));
     int rc = refresh_mask_state(c);
-    if (!rc) rc = materialise_fields(c);
+    if (!rc) rc = fields_for_caller(c);
     if (rc) return rc;
     return read_back(c, u, c->u, n * sizeof(float4));
 }
@@ -886,7 +903,7 @@ int lbm_read_velocity_strided(lbm_ctx* c, int sx, int sy, int sz, float* u, size
     const size_t need = (size_t)nx * ny * nz;
     if (!u || n != need) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided: need %zu x 4 floats (%d x %d x %d samples)", need, nx, ny, nz);
     int rc = refresh_mask_state(c);
-    if (!rc) rc = materialise_fields(c);
+    if (!rc) rc = fields_for_caller(c);
     if (rc) return rc;
     float4* d = nullptr;
     HIPCHK(c, hipMalloc(&d, need * sizeof(float4)));
@@ -903,7 +920,7 @@ int lbm_read_speed(lbm_ctx* c, float* speed, size_t n) {
     NEED(c);
     if (!speed || n != (size_t)field_cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_read_speed: need %lld floats", field_cells(c));
     int rc = refresh_mask_state(c);
-    if (!rc) rc = materialise_fields(c);
+    if (!rc) rc = fields_for_caller(c);
     if (rc) return rc;
     float* d = nullptr;
     HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
@@ -1033,7 +1050,7 @@ int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, ui
         rc = lbm_compute_curl(c);
     } else {  // partial field window: rho/u of the window only, no curl
         rc = refresh_mask_state(c);
-        if (!rc) rc = materialise_fields(c);
+        if (!rc) rc = fields_for_caller(c);
     }
     if (rc) return rc;
     if (d_solid) {  // dense copy of the bit-packed mask in the reference's wire format
