@@ -264,3 +264,37 @@ def test_xcd_row_order(oracle, lbm, dims, scheme, monkeypatch):
     np.testing.assert_array_equal(g.velocity(), o.velocity())
     fluid = o.solid_mask() == 0
     np.testing.assert_array_equal(g.populations()[:, fluid], o.populations()[:, fluid])
+
+
+def test_fused_and_on_demand_fields_agree(oracle, lbm):
+    """A/B makes rho/u on demand from the previous buffer, or -- when the caller read them after its
+    previous step() call -- writes them in the last step of the next call; both must be the reference's
+    per-step values, through parameter and mask changes and a field window"""
+    W, H, D = 96, 20, 18
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D)
+    for s in (o, g):
+        s.init(); s.add_solid(30, 0, 4, 12, 9, 8)
+    o.step(3); g.step(3)                                   # nobody has read yet: on demand
+    np.testing.assert_array_equal(g.density(), o.density())
+    o.step(2); g.step(2)                                   # fused into the second of these steps
+    np.testing.assert_array_equal(g.density(), o.density())
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    np.testing.assert_array_equal(g.curl_field(), (o.compute_curl(), o.curl_field())[1])
+    for s in (o, g):
+        s.set_params(inlet_velocity=0.06, omega_shear=1.8, omega_bulk=1.5)
+    o.step(1); g.step(1)                                   # fused, new parameters
+    for s in (o, g):
+        s.add_solid(60, 5, 2, 8, 8, 8)                     # mask change right after a fused step
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    o.step(4); g.step(4)
+    np.testing.assert_array_equal(g.density(), o.density())
+    g.set_field_window(4, 6)
+    o.step(2); g.step(2)                                   # fused, window only
+    np.testing.assert_array_equal(g.density().reshape(6, -1), o.density().reshape(D, -1)[4:10])
+    g.set_field_window(0, 3)                               # another window of the same step: on demand
+    np.testing.assert_array_equal(g.density().reshape(3, -1), o.density().reshape(D, -1)[0:3])
+    g.set_field_window(0, D)
+    o.step(1); g.step(1)
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    np.testing.assert_array_equal(g.populations(), o.populations())
