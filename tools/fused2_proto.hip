@@ -138,6 +138,78 @@ __global__ __launch_bounds__(NTHREADS) void k_fused2(const float* __restrict__ i
     }
 }
 
+// Variant B: 8 waves per workgroup, every row wave carries TWO rows (r and r + 7), so a wave may use
+// 256 VGPRs: room for the software prefetch of the next layer's 2 x 19 loads, and two independent
+// cells per lane to overlap.  Same tile (64 x 12 + halo), same LDS exchange.
+constexpr int RB = 14, HALF = 7;
+__global__ __launch_bounds__(512) void k_fused2b(const float* __restrict__ in, float* __restrict__ out, int zchunk) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * 64, y0 = 2 + blockIdx.y * 12;
+    const int zs = ZS + blockIdx.z * zchunk, ze = min(zs + zchunk, ZE);
+    int x, r[2];
+    bool act[2], sec[2];
+    if (wave < HALF) {
+        x = x0 + lane; r[0] = wave; r[1] = wave + HALF; act[0] = act[1] = true;
+    } else {  // halo columns: lanes 0..13 -> x0-1, lanes 14..27 -> x0+64, rows 0..13, one cell per lane
+        x = lane < RB ? x0 - 1 : x0 + 64; r[0] = lane % RB; r[1] = 0; act[0] = lane < 2 * RB; act[1] = false;
+    }
+    int y[2], slot[2];
+    const int col = x - x0 + 1;
+    for (int c = 0; c < 2; c++) {
+        y[c] = y0 - 1 + r[c];
+        slot[c] = r[c] * LCOLS + col;
+        sec[c] = wave < HALF && r[c] >= 1 && r[c] <= 12;
+    }
+    float up_prev[2][Q], cur[2][Q], nxt[2][Q], pf[2][Q];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k = 0; k < Q; k++) { up_prev[c][k] = 0.f; cur[c][k] = 0.f; nxt[c][k] = 0.f; pf[c][k] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        if (act[c]) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) pf[c][k] = __builtin_nontemporal_load(in + at(k, x - CX[k], y[c] - CY[k], zs - 1 - CZ[k]));
+        }
+    int buf = 0;
+    for (int L = zs - 1; L <= ze; L++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            if (act[c]) {
+                const Moments m = moments_of(pf[c]);
+                collide_cell(pf[c], m, OMEGA_S, OMEGA_B, nxt[c]);
+                if (L < ze) {
+#pragma unroll
+                    for (int k = 0; k < Q; k++) pf[c][k] = __builtin_nontemporal_load(in + at(k, x - CX[k], y[c] - CY[k], L + 1 - CZ[k]));
+                }
+            }
+        if (L >= zs + 1) {
+            const int z = L - 1;
+            float* my = lds + buf * (16 * RB * LCOLS);
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+                if (act[c]) Put<Q - 1>::run(my, slot[c], up_prev[c], cur[c], nxt[c]);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+                if (sec[c]) {
+                    float f[Q], o[Q];
+                    Get<Q - 1>::run(my, r[c], col, up_prev[c], cur[c], nxt[c], f);
+                    const Moments m = moments_of(f);
+                    collide_cell(f, m, OMEGA_S, OMEGA_B, o);
+#pragma unroll
+                    for (int k = 0; k < Q; k++) __builtin_nontemporal_store(o[k], out + at(k, x, y[c], z));
+                }
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int k = 0; k < Q; k++) { up_prev[c][k] = cur[c][k]; cur[c][k] = nxt[c][k]; }
+    }
+}
+
 static unsigned hash32(unsigned v) { v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16; return v; }
 
 int main(int argc, char** argv) {
@@ -199,5 +271,28 @@ int main(int argc, char** argv) {
     const float t2 = timeit([&] { k_fused2<<<gf, NTHREADS, lds_bytes>>>(A, B, zchunk); }, 10);
     printf("fused two steps, %d rows per tile, prefetch %d : %8.1f us  %7.0f MLUPS  (z split %d, %d workgroups)\n", TY, PREFETCH, t2 * 1e3, 2 * cells_f / (t2 * 1e-3) / 1e6, zsplit,
            gf.x * gf.y * gf.z);
+#if TILE_Y == 12
+    {
+        (void)hipFuncSetAttribute((const void*)k_fused2b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipMemset(B, 0, bytes);
+        k_fused2b<<<gf, 512, lds_bytes>>>(A, B, zchunk);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel B failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+        std::vector<float> hb((size_t)TOTAL), hr((size_t)TOTAL);
+        (void)hipMemcpy(hb.data(), B, bytes, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hr.data(), R, bytes, hipMemcpyDeviceToHost);
+        long long bad = 0;
+        for (int z = ZS; z < ZE; z++)
+            for (int y = 2; y < 2 + NT_Y * TY; y++)
+                for (int k = 0; k < 19; k++)
+                    for (int x = 2; x < W - 2; x++) {
+                        const size_t i = (size_t)z * LAYER + (size_t)y * ROW + (size_t)k * WP + x + XOFF;
+                        if (memcmp(&hb[i], &hr[i], 4) != 0) bad++;
+                    }
+        printf("check B: %lld interior values differ\n", bad);
+        if (bad) return 1;
+        const float t3 = timeit([&] { k_fused2b<<<gf, 512, lds_bytes>>>(A, B, zchunk); }, 10);
+        printf("fused two steps, variant B (8 waves, two rows per wave, prefetch) : %8.1f us  %7.0f MLUPS\n", t3 * 1e3, 2 * cells_f / (t3 * 1e-3) / 1e6);
+    }
+#endif
     return 0;
 }
