@@ -210,6 +210,76 @@ __global__ __launch_bounds__(512) void k_fused2b(const float* __restrict__ in, f
     }
 }
 
+// Variant C: as the first kernel (15 waves, one cell per lane), but the 19 loads of the NEXT layer go
+// straight from global memory into a wave-private LDS staging area (global_load_lds_dword: no VGPRs
+// held while they are in flight), issued as soon as the first step of the current layer has consumed
+// the area.  They travel during the exchange, the second step and its stores.
+constexpr int STAGE_FLOATS = 15 * 19 * 64;
+__global__ __launch_bounds__(960) void k_fused2c(const float* __restrict__ in, float* __restrict__ out, int zchunk) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * 64, y0 = 2 + blockIdx.y * 12;
+    const int zs = ZS + blockIdx.z * zchunk, ze = min(zs + zchunk, ZE);
+    int x, r;
+    bool active = true;
+    if (wave < 14) { r = wave; x = x0 + lane; }
+    else { r = lane % 14; x = lane < 14 ? x0 - 1 : x0 + 64; active = lane < 28; }
+    const int y = y0 - 1 + r;
+    const int col = x - x0 + 1;
+    const int slot = r * LCOLS + col;
+    const bool second = wave >= 1 && wave <= 12;
+    float* exch = lds;
+    float* stage = lds + 16 * 14 * LCOLS + wave * (19 * 64);  // wave-uniform
+
+    auto issue = [&](int L) {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < Q; k++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + at(k, x - CX[k], y - CY[k], L - CZ[k])),
+                                                 (__attribute__((address_space(3))) void*)(stage + k * 64), 4, 0, 0);
+        }
+    };
+    float up_prev[Q], cur[Q], nxt[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) { up_prev[k] = 0.f; cur[k] = 0.f; nxt[k] = 0.f; }
+    issue(zs - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int L = zs - 1; L <= ze; L++) {
+        if (active) {
+            float f[Q];
+#pragma unroll
+            for (int k = 0; k < Q; k++) f[k] = stage[k * 64 + lane];
+            const Moments m = moments_of(f);
+            collide_cell(f, m, OMEGA_S, OMEGA_B, nxt);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area has been read
+        if (L < ze) issue(L + 1);
+        if (L >= zs + 1) {
+            const int z = L - 1;
+            if (active) Put<Q - 1>::run(exch, slot, up_prev, cur, nxt);
+            __syncthreads();
+            if (second) {
+                float f[Q], o[Q];
+                Get<Q - 1>::run(exch, r, col, up_prev, cur, nxt, f);
+                const Moments m = moments_of(f);
+                collide_cell(f, m, OMEGA_S, OMEGA_B, o);
+                // the staged loads of the next layer have had the whole second step to land; waiting for
+                // them HERE keeps the latency of the stores below out of the next iteration's wait
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < Q; k++) __builtin_nontemporal_store(o[k], out + at(k, x, y, z));
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < Q; k++) { up_prev[k] = cur[k]; cur[k] = nxt[k]; }
+    }
+}
+
 static unsigned hash32(unsigned v) { v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16; return v; }
 
 int main(int argc, char** argv) {
@@ -272,6 +342,28 @@ int main(int argc, char** argv) {
     printf("fused two steps, %d rows per tile, prefetch %d : %8.1f us  %7.0f MLUPS  (z split %d, %d workgroups)\n", TY, PREFETCH, t2 * 1e3, 2 * cells_f / (t2 * 1e-3) / 1e6, zsplit,
            gf.x * gf.y * gf.z);
 #if TILE_Y == 12
+    {
+        const size_t lds_c = (size_t)(16 * 14 * LCOLS + STAGE_FLOATS) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)k_fused2c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        (void)hipMemset(B, 0, bytes);
+        k_fused2c<<<gf, 960, lds_c>>>(A, B, zchunk);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel C failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+        std::vector<float> hb((size_t)TOTAL), hr((size_t)TOTAL);
+        (void)hipMemcpy(hb.data(), B, bytes, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hr.data(), R, bytes, hipMemcpyDeviceToHost);
+        long long bad = 0;
+        for (int z = ZS; z < ZE; z++)
+            for (int y = 2; y < 2 + NT_Y * TY; y++)
+                for (int k = 0; k < 19; k++)
+                    for (int x = 2; x < W - 2; x++) {
+                        const size_t i = (size_t)z * LAYER + (size_t)y * ROW + (size_t)k * WP + x + XOFF;
+                        if (memcmp(&hb[i], &hr[i], 4) != 0) bad++;
+                    }
+        printf("check C: %lld interior values differ\n", bad);
+        if (bad) return 1;
+        const float t4 = timeit([&] { k_fused2c<<<gf, 960, lds_c>>>(A, B, zchunk); }, 10);
+        printf("fused two steps, variant C (next layer staged in LDS by global_load_lds) : %8.1f us  %7.0f MLUPS\n", t4 * 1e3, 2 * cells_f / (t4 * 1e-3) / 1e6);
+    }
     {
         (void)hipFuncSetAttribute((const void*)k_fused2b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipMemset(B, 0, bytes);
