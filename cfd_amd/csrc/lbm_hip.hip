@@ -1046,9 +1046,9 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
 int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, uint8_t** d_solid) {
     NEED(c);
     int rc;
-    if (c->g.fnz == c->g.D) {
+    if (d_curl && c->g.fnz == c->g.D) {
         rc = lbm_compute_curl(c);
-    } else {  // partial field window: rho/u of the window only, no curl
+    } else {  // no curl asked for, or a partial field window (rho/u of the window only, no curl)
         rc = refresh_mask_state(c);
         if (!rc) rc = fields_for_caller(c);
     }
@@ -1063,7 +1063,7 @@ int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, ui
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (d_rho) *d_rho = c->rho;
     if (d_u) *d_u = reinterpret_cast<float*>(c->u);
-    if (d_curl) *d_curl = c->curl;
+    if (d_curl) *d_curl = c->g.fnz == c->g.D ? c->curl : nullptr;
     return LBM_OK;
 }
 

@@ -98,7 +98,9 @@ class hip_buffer {
         }
         float *rho = nullptr, *u = nullptr, *curl = nullptr;
         uint8_t* solid = nullptr;
-        LBM_CHECK(m_ctx, lbm_device_fields(m_ctx, &rho, &u, &curl, m_field == field::solid ? &solid : nullptr));
+        // only what this buffer stands for is brought up to date (the curl pass costs 20 B/cell)
+        LBM_CHECK(m_ctx, lbm_device_fields(m_ctx, &rho, &u, m_field == field::curl ? &curl : nullptr,
+                                           m_field == field::solid ? &solid : nullptr));
         switch (m_field) {
             case field::density: return reinterpret_cast<T*>(rho);
             case field::velocity: return reinterpret_cast<T*>(u);

@@ -167,7 +167,8 @@ int lbm_read_classification(lbm_ctx* ctx, uint8_t* cls, size_t n_times_19);
 /* Device pointers of the fields in the reference wire formats, brought up to date and
  * synchronised, for consumers that stay on the GPU (the reference hands d_u/d_solid to its
  * renderer: get_velocity()/get_solid_mask(), lbm_solver.cuh:40-46; renderer.cpp:1382-1389).
- * Any output pointer may be NULL.  d_solid is a dense uint8 copy (0/255) of the packed mask. */
+ * Any output pointer may be NULL, and what is not asked for is not computed (curl: 20 B/cell).
+ * d_solid is a dense uint8 copy (0/255) of the packed mask. */
 int lbm_device_fields(lbm_ctx* ctx, float** d_rho, float** d_u_xyzw, float** d_curl, uint8_t** d_solid);
 
 /* Domains sized to HBM (BASELINE.json configs[4]: 266 GB of populations on a 288 GB GPU) have
