@@ -32,6 +32,13 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 BYTES_PER_CELL = 152           # 19 populations x 4 B x (read + write)
 
 
+# The closed cavity is run at omega_shear = 1.8: with the reference's wind-tunnel default of 1.98 it is
+# under-resolved and blows up after about 700 steps (the CPU oracle does the same), which no benchmark
+# should time; at 1.8 / 1.9 and U = 0.08 it is stable (checked to 30 000 steps on the GPU).  The
+# wind-tunnel configurations keep the reference's defaults (lbm_solver.cuh:9-15).
+CAVITY_PARAMS = dict(inlet_velocity=0.08, omega_shear=1.8, omega_bulk=1.9)
+
+
 def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
     """Oracle (kind "port") on the host cores: the same workload, as many steps as fit the budget
     (at least 2); domains beyond 2^26 cells are cut to their first layers to bound memory and time."""
@@ -43,6 +50,8 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
     D = max(2, min(D, (1 << 26) // (W * H)))
     s = O.Solver(W, H, D, preset)
     s.init()
+    if preset:
+        s.set_params(**CAVITY_PARAMS)
     if obj:
         s.load_mesh(obj)
     s.step(1)                                   # touch every page
@@ -64,6 +73,8 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
         del s
         s1 = O.Solver(128, 128, 64, preset)
         s1.init()
+        if preset:
+            s1.set_params(**CAVITY_PARAMS)
         s1.step(1)
         t0 = time.perf_counter()
         n1 = 0
@@ -91,6 +102,12 @@ def main():
     ap.add_argument("--rehearse-slab", action="store_true",
                     help="N = 1 only: run the z-slab code path of N > 1 (split step, RCCL ring to itself)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: RCCL (version banner at communicator creation) and other
+    # libraries print to fd 1 as well, so everything but that line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from cfd_amd import lbm
@@ -146,6 +163,8 @@ def main():
             solver.set_field_window(0, min(4, D))
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
         solver.init()
+        if preset == lbm.PRESET_CAVITY:
+            solver.set_params(**CAVITY_PARAMS)
         if obstacle:
             solver.load_mesh(car)   # device voxeliser: every slab casts the rays of its own layers
         drv.exchange_mask()
@@ -157,6 +176,8 @@ def main():
         if args.config == 4:
             solver.set_field_window(0, 4)   # sized to HBM: no room for whole-domain rho/u (20 B/cell)
         solver.init()
+        if preset == lbm.PRESET_CAVITY:
+            solver.set_params(**CAVITY_PARAMS)
         if obstacle:
             solver.load_mesh(car)
         step = solver.step
@@ -180,6 +201,12 @@ def main():
         tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, dev_ms = float(tmax[0]), float(tmax[1])
+
+    # the timed state must be a flow, not a blown-up one: look at the density the run ended with
+    import numpy as np
+    rho_end = solver.density()
+    state_finite = bool(np.isfinite(rho_end).all() and rho_end.max() < 10.0)
+    del rho_end
 
     cells = W * H * D
     # solid cells are skipped by the kernel (no loads, no stores): the roofline counts fluid cells only
@@ -220,8 +247,9 @@ def main():
                                    f" (BASELINE.json configs[{args.config}])",
                        "per_gpu_cells": cells, "per_gpu_fluid_cells": fluid, "bytes_per_cell": BYTES_PER_CELL,
                        "layout": "row-interleaved [z][y][k][x], rows padded to 128 B",
+                       "params": CAVITY_PARAMS if preset == lbm.PRESET_CAVITY else "reference defaults (U 0.08, omega 1.98 / 1.90)",
                        "moments_per_step": False},
-            "mlups_per_gpu": round(mlups_total / world, 1),
+            "mlups_per_gpu": round(mlups_total / world, 1), "state_finite": state_finite,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide",
@@ -232,7 +260,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             solver.close()
             out["cpu_baseline"] = cpu_baseline(W, H, D, preset, car if obstacle else None)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
