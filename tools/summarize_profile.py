@@ -1,7 +1,7 @@
 """Condenses gpurun_out/prof_<tag>/ (tools/profile_round.sh) into profiles/<prefix>_<tag>_*.  The PMC byte
 totals follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KiB and at
 half the bytes of coalesced streaming reads on gfx950 (x2), WRITE_SIZE in KiB, exact."""
-import collections, csv, json, os, shutil, sys
+import collections, csv, json, os, re, shutil, sys
 
 tag, prefix, key = sys.argv[1], sys.argv[2], sys.argv[3]   # key into profiles/traffic.json
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,8 +32,13 @@ with open(os.path.join(dst, f"{prefix}_{tag}_pmc_traffic.txt"), "w") as f:
     f.write(f"WRITE_SIZE avg {vals['WRITE_SIZE'][0]:.1f} KiB over {vals['WRITE_SIZE'][1]} dispatches -> x1024 = {write_b:.0f} B\n")
     f.write(f"traffic per launch = {fetch_b + write_b:.0f} B; algorithmic (152 B x {b['roofline']['fluid_cells_per_launch']} fluid cells) = {alg} B; ratio {(fetch_b + write_b) / alg:.4f}\n")
     f.write(f"reads / algorithmic reads = {fetch_b / (alg / 2):.4f}; writes / algorithmic writes = {write_b / (alg / 2):.4f}\n")
+    # k_stream_collide<PRESET, 1, TUNE> is the moments-only pass bench.py runs once after the timed region
+    def inst(name):
+        m = re.search(r"(k_stream_collide|k_aa_step)<([^>]*)>", name)
+        return (m.group(1), m.group(2)) if m else (name, "")
+    stats = [r for r in stats if not (inst(r["Name"])[0] == "k_stream_collide" and inst(r["Name"])[1].split(",")[1].strip() == "1")]
     for r in stats:
-        f.write(f"kernel-trace stats: {r['Calls']} calls, average {float(r['AverageNs']) / 1e3:.2f} us (min {float(r['MinNs']) / 1e3:.2f}, max {float(r['MaxNs']) / 1e3:.2f}); in-bench HIP events: {b['roofline']['launch_ms'] * 1e3:.2f} us\n")
+        f.write(f"kernel-trace stats {inst(r['Name'])[0]}<{inst(r['Name'])[1]}>: {r['Calls']} calls, average {float(r['AverageNs']) / 1e3:.2f} us (min {float(r['MinNs']) / 1e3:.2f}, max {float(r['MaxNs']) / 1e3:.2f}); in-bench HIP events: {b['roofline']['launch_ms'] * 1e3:.2f} us\n")
     if len(stats) > 1:  # AA: the even and the odd phase are two instantiations; bench.py times their mix
         calls = sum(int(r["Calls"]) for r in stats)
         mean = sum(int(r["Calls"]) * float(r["AverageNs"]) for r in stats) / calls
