@@ -13,10 +13,11 @@
 //   * a term f*0 is +-0 and adding it to a running sum never changes the sum's value;
 //   * directions k and inv(k) have cu_k = -cu_inv(k) exactly, share (4.5*cu)*cu and share the
 //     whole non-equilibrium part (Q_ab is even in c).
-// tests/test_collide_exact.py checks this bit-for-bit against the literal oracle.
+// tests/test_abi_and_host.py::test_folded_collision_is_bit_exact checks this bit for bit against the
+// literal oracle.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LBM_HD __host__ __device__ __forceinline__
 #else
 #define LBM_HD inline

@@ -322,6 +322,8 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2, int zorder) {
 //         when asked for (there is no intact previous buffer to recompute them from).  As a z-slab it
 //         writes the halo messages of the boundary layers like MODE 2; with fout == nullptr it ONLY
 //         writes messages (the boundary layer that the directed sweep reaches last must send early).
+// MODE 4: MODE 0 over an explicit list of tiles instead of a box of layers (one entry per wave): the rim of
+//         the two-steps-per-pass scheme (k_fused2.h), i.e. the tiles the fused kernel does not cover.
 // ------------------------------------------------------------------------------------------
 // message layout: see k_halo_pack
 __device__ __forceinline__ void emit_halo(const Geo& g, float* __restrict__ msg, int side, int x, int y,
@@ -347,13 +349,26 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     float* __restrict__ rho_out, float4* __restrict__ u_out,
     Geo g, Params p, int zl_begin, int segsx_log2, int zrev,
     int zl_second, float* __restrict__ msg_bottom, float* __restrict__ msg_top,
-    const float* __restrict__ ob_old, float* __restrict__ ob_new, int want_moments) {
-    const TileId t = tile_of_wave(segsx_log2, zrev);
+    const float* __restrict__ ob_old, float* __restrict__ ob_new, int want_moments,
+    const unsigned long long* __restrict__ tile_list) {
+    TileId t;
+    int zl;
+    if (MODE == 4) {
+        // one list entry per wave: xs | y << 16 | zl << 40 (host side: fused_prepare() in lbm_hip.hip); ~0 pads the list
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned long long e = tile_list[(long long)blockIdx.x * 4 + wave];
+        if (e == ~0ull) return;
+        t.xs = (int)(e & 0xffffu); t.y = (int)((e >> 16) & 0xffffffu); t.lane = threadIdx.x & 63; t.bz = 0;
+        zl = (int)(e >> 40);
+        want_moments = 0;
+    } else {
+        t = tile_of_wave(segsx_log2, zrev);
+        // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
+        // starts on the layers the previous step wrote last (still in the Infinity Cache)
+        zl = MODE == 2 ? (t.bz == 0 ? zl_begin : zl_second)
+                       : zl_begin + ((zrev & ZORDER_REVERSE) ? (int)(gridDim.z - 1 - t.bz) : t.bz);
+    }
     const int y = t.y;
-    // local layer incl. ghost offset (owned: 1..D); zrev walks the layers top-down so that a step
-    // starts on the layers the previous step wrote last (still in the Infinity Cache)
-    const int zl = MODE == 2 ? (t.bz == 0 ? zl_begin : zl_second)
-                             : zl_begin + ((zrev & ZORDER_REVERSE) ? (int)(gridDim.z - 1 - t.bz) : t.bz);
     if (t.xs >= g.Wt || y >= g.H) return;
     const int x = t.xs * 64 + t.lane;
     const unsigned char flag = flags[((long long)(zl - 1) * g.H + y) * g.Wt + t.xs];
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     // outlet column, which a slab's outlet branch reads from the lattice) and all-solid tiles exit
     const bool skip_solid = MODE == 3 && (want_moments & 2);
     if (MODE == 0 || MODE == 3) want_moments = (want_moments & 1) && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
-    if (MODE == 0 && flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
+    if ((MODE == 0 || MODE == 4) && flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
     if (MODE == 3 && skip_solid && flag == 2 && !want_moments && t.xs != g.Wt - 1 &&
         !((zl == 1 && msg_bottom) || (zl == g.D && msg_top)))
         return;

@@ -2,9 +2,11 @@
 //
 // Replaces Engine/src/Physics/lbm_solver.cu of the reference (kernels :37-64, :242-402,
 // :498-513, :612-656 and the host methods around them).  Written for CDNA4 from scratch:
-//   * populations: SoA fp32, 19 planes; a plane is (D+2) z-layers (one ghost layer each side for
-//     the slab halo) of H rows of Wp floats, Wp = W rounded up to 32 floats (128-byte rows);
-//     consecutive planes are separated by a skew so the 19+19 streams do not alias in HBM;
+//   * populations: SoA fp32 runs of Wp floats (W rounded up to 32 floats: every run starts on a
+//     128-byte line), D+2 z-layers (one ghost layer each side for the slab halo).  Default layout is
+//     row-interleaved [z][y][k][x] -- the 19 runs of one (y,z) row form one contiguous chunk --, the
+//     19 skewed planes [k][z][y][x] of round 1a stay selectable; every kernel addresses through the
+//     strides of struct Geo (k_step.h), so the layout changes no result;
 //   * solid mask: bit-packed, one 64-bit word per 64 cells along x (= one wave64 row segment),
 //     with the same ghost layers;
 //   * one wave64 owns 64 consecutive x cells of one (y,z) row.  A byte per such tile, rebuilt
@@ -36,6 +38,7 @@ using namespace d3q19;
 namespace {
 
 #include "k_step.h"
+#include "k_fused2.h"
 #include "k_aa.h"
 #include "k_setup.h"
 #include "k_voxelize.h"
@@ -94,7 +97,10 @@ struct lbm_ctx {
     int ob_cur = 0;
     unsigned long long* prev_mask = nullptr;
     size_t mask_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // lbm_timer_begin / lbm_timer_end
+    hipEvent_t ev_order = nullptr;            // orders the boundary stream behind / ahead of the main stream (split step)
+    bool slide_wait_b = false;                // SLIDE split step: the interior's second chunk must wait for the boundary launches
+    bool prev_touched = false;                // A/B: the previous buffer or the mask changed since the last step
     uint64_t steps = 0, steps_at_begin = 0;
     uint64_t launches = 0, launches_at_begin = 0, last_launches = 0;  // step-kernel launches (a step may take several)
     double last_ms = 0.0;
@@ -104,10 +110,30 @@ struct lbm_ctx {
     long long guard_floats = 0;  // AA: floats allocated in front of f[0]
     int layout = LBM_LAYOUT_ROWS;
     unsigned lds_pad = 0;      // dynamic LDS bytes per block of the step kernel: caps the blocks per CU (occupancy throttle)
+    // ---- two steps per pass (k_fused2.h; A/B, undecomposed, row-interleaved layout) ----
+    bool fused_on = false;         // lbm_opts.two_step / LBM_FUSED
+    bool fused_ready = false;      // eligibility map and rim lists match the current mask
+    bool fused_usable = false;     // ... and enough of the domain takes the fused path for it to pay
+    int f2_ty = 9, f2_stage = 1, f2_nbuf = 2;   // kernel variant (LBM_FUSED_VARIANT="TY,STAGE,NBUF")
+    int f2_zsplit = 0;             // LBM_FUSED_ZSPLIT: z chunks per tile column (0 = chosen by fused_prepare)
+    FusedGrid fg{};
+    float* ft = nullptr;           // third population buffer: holds time t+1 on the rim between its two steps
+    unsigned char* f2_elig = nullptr;   // one byte per workgroup of k_fused2: 1 = its haloed block is plain fluid
+    size_t f2_elig_cap = 0;
+    unsigned long long* rim_list[2] = {nullptr, nullptr};   // [0]: tiles that need t+1 (rim + its neighbours), [1]: the rim
+    size_t rim_n[2] = {0, 0}, rim_cap[2] = {0, 0};          // entries, padded to a multiple of 4
+    long long fused_cells = 0;     // cells one k_fused2 launch updates (twice each)
+    long long rim_cells = 0;       // cells of the rim tiles (second list)
+    std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
+    size_t f2_ev_used = 0;
+    bool timing = false;
+    uint64_t fused_launches = 0, fused_launches_at_begin = 0, last_fused_launches = 0;
+    double last_fused_ms = 0.0;
     std::string err;
 };
 
 static thread_local std::string g_create_error;
+constexpr int MAX_DEVICES = 64;
 
 static int fail(lbm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -198,25 +224,36 @@ static int refresh_mask_state(lbm_ctx* c) {
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream,
                            c->f[c->cur], c->f[1 - c->cur], c->mask, c->g);
         HIPCHK(c, hipGetLastError());
+        c->prev_touched = true;  // the previous buffer no longer is what the last step read
+        if (c->ft) {  // the rim's intermediate buffer keeps the frozen solid cells too (the outlet branch reads them)
+            hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream, c->f[c->cur], c->ft, c->mask, c->g);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     c->mask_dirty = false;
+    c->fused_ready = false;  // tile flags changed: the fused path's eligibility map and rim lists are stale
     return LBM_OK;
 }
 
 template <int MODE>
 static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, const Params& p, int zl_begin, int nlayers,
                                  int zl_second = 0, float* msg_bottom = nullptr, float* msg_top = nullptr,
-                                 int want_moments = 0, hipStream_t on_stream = nullptr) {
+                                 int want_moments = 0, hipStream_t on_stream = nullptr,
+                                 const unsigned long long* tile_list = nullptr, size_t ntiles = 0) {
     if (nlayers <= 0) return LBM_OK;
     hipStream_t stream = on_stream ? on_stream : ((MODE == 2 && c->stream_b) ? c->stream_b : c->stream);
     const int segsx = 1 << c->segsx_log2;
     dim3 grid((c->g.Wt + segsx - 1) / segsx, (c->g.H + (4 / segsx) - 1) / (4 / segsx), nlayers);
+    if (MODE == 4) {  // one wave per list entry, four entries per workgroup
+        if (ntiles == 0) return LBM_OK;
+        grid = dim3((unsigned)(ntiles / 4));
+    }
     if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
     const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0);
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
     hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
                        c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top,     \
-                       c->ob[c->ob_cur], c->ob[1 - c->ob_cur], want_moments)
+                       c->ob[c->ob_cur], c->ob[1 - c->ob_cur], want_moments, tile_list)
 #define LBM_LAUNCH_T(PRESET)                          \
     switch (c->tune & 3) {                            \
         case 0: LBM_LAUNCH(PRESET, 0); break;         \
@@ -229,7 +266,7 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
 #undef LBM_LAUNCH_T
 #undef LBM_LAUNCH
     HIPCHK(c, hipGetLastError());
-    if (MODE != 1) c->launches++;
+    if (MODE != 1 && MODE != 4) c->launches++;
     return LBM_OK;
 }
 
@@ -333,6 +370,13 @@ static int slide_layers(lbm_ctx* c, int zl_begin, int nlayers, int want_moments,
     for (int i = 0; i < nchunks; i++) {
         const int j = up ? nchunks - 1 - i : i;
         const int nl = nlayers - j * K < K ? nlayers - j * K : K;
+        // Split step on two streams: the boundary launches (lbm_step_boundary_layers, on the side stream)
+        // read the input layers around the layer the sweep starts with, and from the second chunk on the
+        // interior's output lands on exactly those layers.  The first chunk still overlaps with them.
+        if (i == 1 && c->slide_wait_b) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));
+            c->slide_wait_b = false;
+        }
         int rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, zl_begin + j * K, nl, 0, msg_bottom, msg_top,
                                           want_moments | (c->slide_pristine ? 2 : 0));
         if (rc) return rc;
@@ -363,6 +407,219 @@ static inline float* halo_lattice(lbm_ctx* c) {
     return c->split_phase ? c->f[1 - c->cur] : c->f[c->cur];
 }
 
+// ------------------------------------------------------------------------------------------
+// two steps per pass (k_fused2.h)
+// ------------------------------------------------------------------------------------------
+// The fused kernel covers the blocks (64 x TY tile, chunk of z layers) whose haloed neighbourhood is plain
+// fluid; everything else -- the rim: wall rows and layers, tiles near solids, ragged remainders -- takes two
+// ordinary steps through the third buffer `ft`:
+//     k_fused2            f[cur] -> f[1-cur]   (time t -> t+2, covered tiles)
+//     k_stream_collide<4> f[cur] -> ft         (t -> t+1 on the rim and on every tile next to it)
+//     k_stream_collide<4> ft     -> f[1-cur]   (t+1 -> t+2 on the rim)
+// The three launches write disjoint cells; the second pair is ordered by the stream.  fused_prepare() derives
+// block eligibility and the two tile lists from the tile flags (on the host: it runs once per mask change).
+static bool fused_applies(const lbm_ctx* c) {
+    return c->fused_on && c->scheme == LBM_SCHEME_AB && !c->g.slab && c->layout == LBM_LAYOUT_ROWS;
+}
+
+struct F2Variant { int ty, stage, nbuf; };
+static const F2Variant kF2Variants[] = {{9, 1, 2}, {12, 1, 1}, {13, 1, 1}, {9, 0, 2}, {12, 0, 2}};
+
+template <int PRESET, int TY, int STAGE, int NBUF>
+static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout) {
+    static bool attr_set[MAX_DEVICES] = {false};
+    auto kern = k_fused2<PRESET, TY, STAGE, NBUF>;
+    const size_t lds = f2_lds_bytes(TY, STAGE, NBUF);
+    if (!attr_set[c->device]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[c->device] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(c->fg.nbx, c->fg.nby, c->fg.nbz), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_elig,
+                       c->g, c->p, c->fg);
+    return hipGetLastError();
+}
+template <int TY, int STAGE, int NBUF>
+static hipError_t launch_fused_preset(lbm_ctx* c, const float* fin, float* fout) {
+    return c->preset == LBM_PRESET_CAVITY ? launch_fused_variant<LBM_PRESET_CAVITY, TY, STAGE, NBUF>(c, fin, fout)
+                                          : launch_fused_variant<LBM_PRESET_WIND_TUNNEL_REF, TY, STAGE, NBUF>(c, fin, fout);
+}
+static hipError_t launch_fused(lbm_ctx* c, const float* fin, float* fout) {
+    const int key = c->f2_ty * 100 + c->f2_stage * 10 + c->f2_nbuf;
+    switch (key) {
+        case 912: return launch_fused_preset<9, 1, 2>(c, fin, fout);
+        case 1211: return launch_fused_preset<12, 1, 1>(c, fin, fout);
+        case 1311: return launch_fused_preset<13, 1, 1>(c, fin, fout);
+        case 902: return launch_fused_preset<9, 0, 2>(c, fin, fout);
+        case 1202: return launch_fused_preset<12, 0, 2>(c, fin, fout);
+    }
+    return hipErrorInvalidValue;
+}
+
+static int fused_upload(lbm_ctx* c, void** dev, size_t* cap, const void* host, size_t bytes) {
+    if (bytes > *cap) {
+        if (*dev) (void)hipFree(*dev);
+        *dev = nullptr; *cap = 0;
+        HIPCHK(c, hipMalloc(dev, bytes));
+        *cap = bytes;
+    }
+    if (bytes) HIPCHK(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return LBM_OK;
+}
+
+// the mask is clean (refresh_mask_state ran).  Leaves fused_usable = false when the fused path does not apply
+// to this domain or would not pay; that is not an error.
+static int fused_prepare(lbm_ctx* c) {
+    if (c->fused_ready) return LBM_OK;
+    c->fused_ready = true;
+    c->fused_usable = false;
+    const Geo& g = c->g;
+    const int TY = c->f2_ty;
+    // rows [2, H-2) and layers z in [2, D-2) can take the fused path: the haloed blocks must stay off the wall
+    // rows / layers, whose tiles are flagged as boundary tiles
+    if (g.H < 6 || g.D < 6 || g.Wt >= 65536 || g.H >= (1 << 24) || g.D + 2 >= (1 << 24)) return LBM_OK;
+    const long long layer_b = g.layer * 4;
+    if (layer_b >= (1ll << 30)) return LBM_OK;                      // 32-bit byte offsets inside a z chunk (k_fused2.h)
+    FusedGrid fg;
+    fg.nbx = g.Wt;
+    fg.y_first = 2; fg.y_end = g.H - 2;
+    fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
+    fg.zl_first = 3; fg.zl_end = g.D - 1;
+    const int nz = fg.zl_end - fg.zl_first;
+    const int max_chunk = (int)std::min<long long>(nz, ((1ll << 32) - 1) / layer_b - 5);
+    if (max_chunk < 1) return LBM_OK;
+    int ncu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    // z chunks per tile column: whole rounds of one workgroup per CU, against the two redundant first-step
+    // layers every chunk starts with
+    int best_nbz = 0;
+    double best_eff = -1.0;
+    for (int nbz = 1; nbz <= std::min(nz, 256); nbz++) {
+        const int zc = (nz + nbz - 1) / nbz;
+        if (zc > max_chunk) continue;
+        if ((nz + zc - 1) / zc != nbz) continue;                     // the same chunk length as a smaller count
+        const long long wgs = (long long)fg.nbx * fg.nby * nbz;
+        const double eff = (double)wgs / (double)((wgs + ncu - 1) / ncu * ncu) * zc / (zc + 2.0);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best_nbz = nbz; }
+    }
+    if (c->f2_zsplit > 0) {
+        const int zc = (nz + c->f2_zsplit - 1) / c->f2_zsplit;
+        if (zc <= max_chunk) best_nbz = (nz + zc - 1) / zc;
+    }
+    if (best_nbz == 0) return LBM_OK;
+    fg.zchunk = (nz + best_nbz - 1) / best_nbz;
+    fg.nbz = (nz + fg.zchunk - 1) / fg.zchunk;
+
+    // tile flags -> host
+    const long long ntiles = (long long)g.D * g.H * g.Wt;
+    std::vector<unsigned char> fl((size_t)ntiles);
+    HIPCHK(c, hipMemcpyAsync(fl.data(), c->flags, (size_t)ntiles, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto tile = [&](int xs, int y, int z) -> size_t { return ((size_t)z * g.H + y) * g.Wt + xs; };   // z = zl - 1
+
+    // block eligibility: every tile the block's first step touches (one more tile in x, one row in y, one
+    // layer in z on every side) is an interior tile (flag 0)
+    const size_t nblocks = (size_t)fg.nbx * fg.nby * fg.nbz;
+    std::vector<unsigned char> elig(nblocks, 0), covered((size_t)ntiles, 0);
+    long long fused_cells = 0;
+#pragma omp parallel for collapse(2) schedule(dynamic, 8) reduction(+ : fused_cells)
+    for (int bz = 0; bz < fg.nbz; bz++)
+        for (int by = 0; by < fg.nby; by++) {
+            const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
+            const int zs = fg.zl_first + bz * fg.zchunk, ze = std::min(zs + fg.zchunk, fg.zl_end);
+            for (int bx = 0; bx < fg.nbx; bx++) {
+                bool ok = true;
+                for (int z = zs - 2; z <= ze - 1 && ok; z++)
+                    for (int y = y0 - 1; y <= y0 + tyn && ok; y++)
+                        for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
+                            if (fl[tile(xs, y, z)] != 0) { ok = false; break; }
+                if (!ok) continue;
+                elig[((size_t)bz * fg.nby + by) * fg.nbx + bx] = 1;
+                for (int z = zs - 1; z <= ze - 2; z++)
+                    for (int y = y0; y < y0 + tyn; y++) covered[tile(bx, y, z)] = 1;
+                fused_cells += (long long)std::min(64, g.W - bx * 64) * tyn * (ze - zs);
+            }
+        }
+    if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
+
+    // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
+    // t+1 values from the 26 neighbouring tiles, so the first rim step covers the rim dilated by one tile
+    std::vector<unsigned char> rim((size_t)ntiles), a((size_t)ntiles), b((size_t)ntiles);
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < ntiles; i++) rim[(size_t)i] = !covered[(size_t)i] && fl[(size_t)i] != 2;
+#pragma omp parallel for schedule(static)
+    for (long long rowi = 0; rowi < (long long)g.D * g.H; rowi++) {      // dilate along x
+        const unsigned char* r = rim.data() + (size_t)rowi * g.Wt;
+        unsigned char* o = a.data() + (size_t)rowi * g.Wt;
+        for (int xs = 0; xs < g.Wt; xs++) o[xs] = r[xs] | (xs > 0 ? r[xs - 1] : 0) | (xs + 1 < g.Wt ? r[xs + 1] : 0);
+    }
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < g.D; z++)                                        // along y
+        for (int y = 0; y < g.H; y++)
+            for (int xs = 0; xs < g.Wt; xs++)
+                b[tile(xs, y, z)] = a[tile(xs, y, z)] | (y > 0 ? a[tile(xs, y - 1, z)] : 0) | (y + 1 < g.H ? a[tile(xs, y + 1, z)] : 0);
+#pragma omp parallel for schedule(static)
+    for (int z = 0; z < g.D; z++)                                        // along z
+        for (int y = 0; y < g.H; y++)
+            for (int xs = 0; xs < g.Wt; xs++)
+                a[tile(xs, y, z)] = b[tile(xs, y, z)] | (z > 0 ? b[tile(xs, y, z - 1)] : 0) | (z + 1 < g.D ? b[tile(xs, y, z + 1)] : 0);
+    std::vector<unsigned long long> list[2];
+    long long rim_cells = 0;
+    for (int z = 0; z < g.D; z++)
+        for (int y = 0; y < g.H; y++)
+            for (int xs = 0; xs < g.Wt; xs++) {
+                const size_t t = tile(xs, y, z);
+                if (fl[t] == 2) continue;
+                const unsigned long long e = (unsigned long long)xs | ((unsigned long long)y << 16) | ((unsigned long long)(z + 1) << 40);
+                if (a[t]) list[0].push_back(e);
+                if (rim[t]) { list[1].push_back(e); rim_cells += std::min(64, g.W - xs * 64); }
+            }
+    for (auto& l : list)
+        while (l.size() % 4) l.push_back(~0ull);
+
+    if (!c->ft) {  // third buffer; without it the fused path stays off
+        if (hipMalloc(&c->ft, c->pop_bytes) != hipSuccess) { (void)hipGetLastError(); c->ft = nullptr; return LBM_OK; }
+        hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream, c->f[c->cur], c->ft, c->mask, c->g);
+        HIPCHK(c, hipGetLastError());
+    }
+    int rc = fused_upload(c, (void**)&c->f2_elig, &c->f2_elig_cap, elig.data(), elig.size());
+    for (int i = 0; i < 2 && !rc; i++) {
+        rc = fused_upload(c, (void**)&c->rim_list[i], &c->rim_cap[i], list[i].data(), list[i].size() * sizeof(unsigned long long));
+        c->rim_n[i] = list[i].size();
+    }
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the host vectors go out of scope
+    c->fg = fg;
+    c->fused_cells = fused_cells;
+    c->rim_cells = rim_cells;
+    c->fused_usable = true;
+    return LBM_OK;
+}
+
+// two time steps: t (f[cur]) -> t+2 (f[1-cur])
+static int fused_pair(lbm_ctx* c) {
+    const float* in = c->f[c->cur];
+    float* out = c->f[1 - c->cur];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {  // device time of the dominant kernel alone, for the roofline figure
+        if (c->f2_ev_used + 2 > c->f2_ev.size() && c->f2_ev.size() < 1024) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { c->f2_ev.push_back(a); c->f2_ev.push_back(b); }
+        }
+        if (c->f2_ev_used + 2 <= c->f2_ev.size()) { e0 = c->f2_ev[c->f2_ev_used]; e1 = c->f2_ev[c->f2_ev_used + 1]; c->f2_ev_used += 2; }
+    }
+    if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipError_t e = launch_fused(c, in, out);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "k_fused2 launch failed: %s", hipGetErrorString(e));
+    if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
+    c->fused_launches++;
+    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[0], c->rim_n[0]);
+    if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[1], c->rim_n[1]);
+    if (rc) return rc;
+    c->cur = 1 - c->cur;
+    return LBM_OK;
+}
+
 // bring rho/u up to date: what the reference's per-step writes would hold right now
 static int materialise_fields(lbm_ctx* c) {
     if (c->g.fnz == 0) return fail(c, LBM_ERR_STATE, "the field window is empty (lbm_set_field_window)");
@@ -374,6 +631,10 @@ static int materialise_fields(lbm_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else if (c->scheme != LBM_SCHEME_AB) {
         return fail(c, LBM_ERR_STATE, "in-place schemes: rho/u of a new field window exist after the next lbm_step()");
+    } else if (c->prev_touched) {
+        // the fields of the last step were settled with the old mask and then dropped by a window change;
+        // the buffer they came from has been re-frozen with the new mask since
+        return fail(c, LBM_ERR_STATE, "the mask or the populations changed since the last step: rho/u of another field window exist after the next lbm_step()");
     } else {
         // the last step read f[1-cur]; it is still intact (A/B), so the same gather gives the
         // same post-stream moments (lbm_solver.cu:320-337)
@@ -541,6 +802,17 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->ab_chunk = c->aa_chunk = auto_chunk(g, c->segsx_log2);
     if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = c->aa_chunk = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
+    c->fused_on = o.two_step != LBM_TWO_STEP_OFF;
+    if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
+    if (const char* t = getenv("LBM_FUSED_VARIANT")) {
+        int ty = 0, st = 0, nb = 0;
+        bool known = false;
+        if (sscanf(t, "%d,%d,%d", &ty, &st, &nb) == 3)
+            for (const F2Variant& v : kF2Variants) known = known || (v.ty == ty && v.stage == st && v.nbuf == nb);
+        if (!known) { delete c; return fail(nullptr, LBM_ERR_INVALID, "lbm_create: LBM_FUSED_VARIANT=%s is not a compiled variant", t); }
+        c->f2_ty = ty; c->f2_stage = st; c->f2_nbuf = nb;
+    }
     c->pop_bytes = (size_t)c->pop_floats * sizeof(float);
 
     auto cleanup = [&](int code) {
@@ -555,6 +827,10 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
             return cleanup(LBM_ERR_HIP);                                                           \
         }                                                                                          \
     } while (0)
+    if (o.boundary_stream && !o.stream) {
+        fail(nullptr, LBM_ERR_INVALID, "lbm_create: lbm_opts.boundary_stream needs lbm_opts.stream (the caller orders the two streams)");
+        return cleanup(LBM_ERR_INVALID);
+    }
     if (o.stream) {
         c->stream = (hipStream_t)o.stream;
         c->stream_b = (hipStream_t)o.boundary_stream;
@@ -597,6 +873,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     CR(hipMalloc(&c->flags, (size_t)depth * height * g.Wt));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
+    CR(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
 #undef CR
     *out = c;
     return LBM_OK;
@@ -610,9 +887,12 @@ int lbm_destroy(lbm_ctx* c) {
     if (!c->f1_in_alloc0) hipFree(c->f[1]);
     hipFree(c->mask); hipFree(c->flags);
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
+    hipFree(c->ft); hipFree(c->f2_elig); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
+    for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
     hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_order) hipEventDestroy(c->ev_order);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return LBM_OK;
@@ -637,7 +917,9 @@ int lbm_init(lbm_ctx* c) {
         c->slide_pristine = c->scheme == LBM_SCHEME_SLIDE;
         c->slide_stepped = false;
     }
+    if (c->ft) c->mask_dirty = true;  // the third buffer's frozen solid cells must follow (k_sync_solid)
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
+    c->prev_touched = false;
     c->curl_valid = false;
     return LBM_OK;
 }
@@ -658,7 +940,9 @@ int lbm_get_params(lbm_ctx* c, float* inlet_velocity, float* omega_shear, float*
 
 // the fields the reference would hold were written with the OLD mask: settle them first
 static int before_mask_change(lbm_ctx* c) {
-    if (c->fields == FIELDS_STALE) {
+    // nothing to settle without a field window; in place (AA, SLIDE) stale fields only arise from a moved
+    // window and are refilled by the next lbm_step()
+    if (c->fields == FIELDS_STALE && c->g.fnz > 0 && c->scheme == LBM_SCHEME_AB) {
         int rc = refresh_mask_state(c);
         if (rc) return rc;
         return materialise_fields(c);
@@ -798,7 +1082,19 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         rc = ensure_field_buffers(c);
         if (rc) return rc;
     }
-    for (int s = 0; s < nsteps; s++) {
+    int s = 0;
+    // Two steps per pass wherever the batch allows it.  The LAST step of a call always runs alone: rho/u of
+    // that step are recomputed on demand from the buffer it read, which a fused pair would skip over.
+    if (nsteps >= 3 && fused_applies(c)) {
+        rc = fused_prepare(c);
+        if (rc) return rc;
+        if (c->fused_usable)
+            for (; s + 2 < nsteps; s += 2) {
+                rc = fused_pair(c);
+                if (rc) return rc;
+            }
+    }
+    for (; s < nsteps; s++) {
         rc = launch_ab_layers(c, 1, c->g.D, fuse && s == nsteps - 1);
         if (rc) return rc;
         c->cur = 1 - c->cur;  // std::swap(d_f, d_f_new), lbm_solver.cu:490
@@ -807,6 +1103,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     c->p_last = c->p;
     c->steps += (uint64_t)nsteps;
     c->fields = fuse ? FIELDS_VALID : FIELDS_STALE;
+    c->prev_touched = false;
     c->fields_wanted = false;
     c->curl_valid = false;
     return LBM_OK;
@@ -1023,11 +1320,8 @@ int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_write_populations: need %lld floats", cells(c) * Q);
     if (c->scheme == LBM_SCHEME_AA) return aa_copy_populations(c, const_cast<float*>(f), false);
     int rc = LBM_OK;
-    if (c->fields == FIELDS_STALE) {  // settle rho/u of the last step before touching solid cells
-        rc = refresh_mask_state(c);
-        if (!rc) rc = materialise_fields(c);
-        if (rc) return rc;
-    }
+    rc = before_mask_change(c);  // settle rho/u of the last step before touching solid cells
+    if (rc) return rc;
     rc = copy_populations(c, const_cast<float*>(f), false);
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_SLIDE) {  // the outlet column's side array follows the new populations
@@ -1084,6 +1378,11 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->last_timed_ms = c->last_ms;
     out->last_timed_steps = c->last_steps;
     out->last_timed_launches = c->last_launches;
+    out->population_bytes += c->ft ? c->pop_bytes : 0;
+    out->fused_cells = (uint64_t)(c->fused_usable ? c->fused_cells : 0);
+    out->rim_cells = (uint64_t)(c->fused_usable ? c->rim_cells : 0);
+    out->last_timed_fused_launches = c->last_fused_launches;
+    out->last_timed_fused_ms = c->last_fused_ms;
     return LBM_OK;
 }
 
@@ -1093,6 +1392,13 @@ int lbm_timer_begin(lbm_ctx* c) {
     if (rc) return rc;
     c->steps_at_begin = c->steps;
     c->launches_at_begin = c->launches;
+    c->fused_launches_at_begin = c->fused_launches;
+    c->f2_ev_used = 0;
+    c->timing = true;
+    if (fused_applies(c)) {  // keep the one-off host work of the fused path out of the timed region as well
+        rc = fused_prepare(c);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return LBM_OK;
 }
@@ -1106,6 +1412,16 @@ int lbm_timer_end(lbm_ctx* c) {
     c->last_ms = ms;
     c->last_steps = c->steps - c->steps_at_begin;
     c->last_launches = c->launches - c->launches_at_begin;
+    c->last_fused_launches = c->fused_launches - c->fused_launches_at_begin;
+    c->timing = false;
+    double fms = 0.0;
+    for (size_t i = 0; i + 1 < c->f2_ev_used; i += 2) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, c->f2_ev[i], c->f2_ev[i + 1]) == hipSuccess) fms += t;
+    }
+    // launches beyond the event pool are priced at the mean of the measured ones
+    const size_t measured = c->f2_ev_used / 2;
+    c->last_fused_ms = measured ? fms * (double)c->last_fused_launches / (double)measured : 0.0;
     return LBM_OK;
 }
 
@@ -1238,8 +1554,8 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
     int rc = refresh_mask_state(c);
     if (rc) return rc;
     if (was_dirty && c->stream_b) {  // the set-up kernels ran on the main stream: order the side stream behind them
-        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev1, 0));
+        HIPCHK(c, hipEventRecord(c->ev_order, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev_order, 0));
     }
     if (c->scheme == LBM_SCHEME_AA) {
         // in place: the boundary layers, then two small pack launches (the layout of the moment decides
@@ -1265,6 +1581,10 @@ int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
         if (!rc && D > 1)
             rc = launch_stream_collide<3>(c, slide_in(c), nullptr, c->p, last, 1, 0, d_msg_bottom, d_msg_top, skip, bs);
         if (rc) return rc;
+        if (bs != c->stream) {  // see slide_layers(): the interior's later chunks overwrite what these launches read
+            HIPCHK(c, hipEventRecord(c->ev_order, bs));
+            c->slide_wait_b = true;
+        }
         c->split_phase = 1;
         return LBM_OK;
     }
@@ -1302,6 +1622,10 @@ int lbm_step_interior_layers(lbm_ctx* c) {
     if (c->scheme == LBM_SCHEME_SLIDE) {
         const int D = c->g.D, want = c->g.fnz > 0;
         rc = slide_layers(c, 2, D - 2, want);
+        if (!rc && c->slide_wait_b) {  // fewer than two interior chunks: nothing waited for the boundary launches yet
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));
+            c->slide_wait_b = false;
+        }
         // the boundary layer the sweep ends with (its message left in lbm_step_boundary_layers)
         if (!rc && D > 1)
             rc = launch_stream_collide<3>(c, slide_in(c), slide_out(c), c->p, slide_up(c) ? 1 : D, 1, 0, nullptr, nullptr,
@@ -1324,6 +1648,7 @@ int lbm_step_finish(lbm_ctx* c) {
     c->p_last = c->p;
     c->steps += 1;
     c->fields = c->scheme == LBM_SCHEME_AB ? FIELDS_STALE : FIELDS_VALID;
+    c->prev_touched = false;
     c->curl_valid = false;
     c->split_phase = 0;
     return LBM_OK;

@@ -19,8 +19,10 @@ SCHEME_SLIDE = 2
 LAYOUT_DEFAULT = 0
 LAYOUT_PLANES = 1
 LAYOUT_ROWS = 2
+TWO_STEP_AUTO = 0
+TWO_STEP_OFF = 1
 
-ABI_VERSION = 1   # include/lbm_abi.h LBM_ABI_VERSION
+ABI_VERSION = 2   # include/lbm_abi.h LBM_ABI_VERSION
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
@@ -37,13 +39,15 @@ class Opts(C.Structure):
                 ("scheme", C.c_int32), ("z0", C.c_int32), ("depth_global", C.c_int32),
                 ("stream", C.c_void_p), ("plane_skew_bytes", C.c_int32),
                 ("layout", C.c_int32), ("boundary_stream", C.c_void_p),
-                ("slide_chunk", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("slide_chunk", C.c_int32), ("two_step", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
     _fields_ = [("steps", C.c_uint64), ("cells", C.c_uint64), ("bytes_per_cell", C.c_uint64),
                 ("population_bytes", C.c_uint64), ("last_timed_ms", C.c_double),
-                ("last_timed_steps", C.c_uint64), ("last_timed_launches", C.c_uint64)]
+                ("last_timed_steps", C.c_uint64), ("last_timed_launches", C.c_uint64),
+                ("fused_cells", C.c_uint64), ("rim_cells", C.c_uint64),
+                ("last_timed_fused_launches", C.c_uint64), ("last_timed_fused_ms", C.c_double)]
 
 
 # every symbol include/lbm_abi.h declares, with its ctypes signature
@@ -138,7 +142,7 @@ class Solver:
 
     def __init__(self, W, H, D, preset=PRESET_WIND_TUNNEL, device=-1, z0=0, depth_global=0,
                  stream=None, plane_skew_bytes=-1, scheme=SCHEME_AB, boundary_stream=None,
-                 layout=LAYOUT_DEFAULT, slide_chunk=0):
+                 layout=LAYOUT_DEFAULT, slide_chunk=0, two_step=TWO_STEP_AUTO):
         self._lib = load_library()
         self.W, self.H, self.D = W, H, D
         self.n = W * H * D
@@ -156,6 +160,7 @@ class Solver:
         o.layout = layout
         o.boundary_stream = boundary_stream
         o.slide_chunk = slide_chunk
+        o.two_step = two_step
         self._ctx = _ctx()
         rc = self._lib.lbm_create(C.byref(self._ctx), W, H, D, C.byref(o))
         if rc != 0:

@@ -48,15 +48,16 @@ class HipSlabEngine:
         # The context runs on torch streams of its own (non-null handles: handing over the legacy
         # default stream, handle 0, would make the library create a private stream that
         # torch.distributed knows nothing about).  `stream` carries the interior update and the
-        # unpack; `bstream` (high priority) carries the boundary layers, and the driver makes it
-        # torch's current stream around the exchange so RCCL orders itself behind them -- the
-        # boundary layers and the messages then run BESIDE the interior kernel, not before it.
+        # unpack; `bstream` carries the boundary layers, and the driver makes it torch's current
+        # stream around the exchange so RCCL orders itself behind them -- the boundary layers and the
+        # messages then run BESIDE the interior kernel, not before it.  Both streams have the SAME
+        # priority: a high-priority side stream deadlocked in the event waits between the two streams
+        # on this ROCm, so that mode no longer exists.
         self.stream = torch.cuda.Stream(device=self.device)
-        mode = os.environ.get("LBM_SLAB_STREAMS", "2" if two_streams else "1")
-        two_streams = mode in ("2", "2p")
+        two_streams = os.environ.get("LBM_SLAB_STREAMS", "2" if two_streams else "1") == "2"
         self.bstream = None
         if two_streams:
-            self.bstream = torch.cuda.Stream(device=self.device, priority=-1 if mode == "2p" else 0)
+            self.bstream = torch.cuda.Stream(device=self.device)
         self.solver = lbm.Solver(W, H, D, preset=preset, device=self.device.index, z0=z0,
                                  depth_global=depth_global, stream=self.stream.cuda_stream, scheme=scheme,
                                  boundary_stream=self.bstream.cuda_stream if two_streams else None)
@@ -89,9 +90,11 @@ class HipSlabEngine:
             return torch.zeros(self.W * self.H, dtype=torch.uint8, device=self.device)
 
     def halo_pack(self, side, msg):
+        self._check_message(msg)
         self.solver._chk(self._lib.lbm_halo_pack(self._ctx, side, msg.data_ptr()))
 
     def halo_unpack(self, side, msg):
+        self._check_message(msg)
         self.solver._chk(self._lib.lbm_halo_unpack(self._ctx, side, msg.data_ptr()))
 
     def get_mask_layer(self, side):
@@ -107,13 +110,27 @@ class HipSlabEngine:
         self.solver._chk(self._lib.lbm_halo_set_mask_ghost(
             self._ctx, side, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size))
 
+    def _check_message(self, msg):
+        """The library takes raw device pointers and cannot see a buffer's size: a message that is too
+        short, on another device or not fp32 would be written out of bounds by the boundary kernel."""
+        if msg is None:
+            return
+        if msg.dtype != torch.float32 or msg.device != self.device or not msg.is_contiguous() \
+                or msg.numel() < self.message_floats():
+            raise ValueError(f"halo message must be a contiguous float32 tensor of >= {self.message_floats()} "
+                             f"elements on {self.device} (got {msg.dtype}, {msg.numel()} on {msg.device})")
+
     def step_boundary(self, msg_bottom=None, msg_top=None):
         """boundary layers; the outgoing messages are written by the same launch"""
+        self._check_message(msg_bottom)
+        self._check_message(msg_top)
         self.solver._chk(self._lib.lbm_step_boundary_layers(
             self._ctx, None if msg_bottom is None else msg_bottom.data_ptr(),
             None if msg_top is None else msg_top.data_ptr()))
 
     def halo_unpack_both(self, from_below, from_above):
+        self._check_message(from_below)
+        self._check_message(from_above)
         self.solver._chk(self._lib.lbm_halo_unpack_both(
             self._ctx, None if from_below is None else from_below.data_ptr(),
             None if from_above is None else from_above.data_ptr()))
@@ -125,6 +142,23 @@ class HipSlabEngine:
 
     def step_finish(self):
         self.solver._chk(self._lib.lbm_step_finish(self._ctx))
+
+
+class LoopbackP2P:
+    """Transport of a one-rank ring (every message goes to the sender itself) as device copies on
+    torch's current stream: what RCCL's send/recv to self does, without a communicator.  Lets one GPU
+    run SlabSolver's real schedule -- the two-stream ordering included -- in tests."""
+
+    @staticmethod
+    def exchange(items):
+        for send, dst, recv, src in items:
+            if dst is not None and src is not None:
+                recv.copy_(send, non_blocking=True)
+        return []
+
+    @staticmethod
+    def wait(handle):
+        pass
 
 
 class TorchP2P:

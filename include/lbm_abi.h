@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 1
+#define LBM_ABI_VERSION 2
 #define LBM_Q 19
 
 typedef struct lbm_ctx lbm_ctx;
@@ -91,8 +91,16 @@ typedef struct lbm_opts {
      * it; the CALLER orders the two streams (see cfd_amd/slab.py).  NULL = use `stream`. */
     void*   boundary_stream;
     int32_t slide_chunk;   /* LBM_SCHEME_SLIDE: layers per launch (spare layers = chunk + 2); 0 = library default (32) */
-    int32_t reserved[3];
+    /* LBM_SCHEME_AB, undecomposed, row-interleaved layout: lbm_step(ctx, n >= 3) advances TWO time steps per pass
+     * over HBM wherever a block of tiles is plain fluid (k_fused2.h: 76 B x (1 + halo) read + 76 B written per two
+     * updates instead of 304 B) and takes the rim -- walls, tiles near solids -- through two ordinary steps via a
+     * third population buffer (allocated on first use: +50 % population memory).  Results are bit-identical
+     * to single steps; the last step of every call is a single step (its rho/u stay available on demand).
+     * LBM_TWO_STEP_AUTO = on where it applies. */
+    int32_t two_step;      /* LBM_TWO_STEP_* */
+    int32_t reserved[2];
 } lbm_opts;
+enum { LBM_TWO_STEP_AUTO = 0, LBM_TWO_STEP_OFF = 1 };
 
 /* Per-context counters for benches (device time is measured with HIP events on the
  * context's stream around the lbm_step calls issued between timer_begin and timer_end). */
@@ -103,8 +111,14 @@ typedef struct lbm_stats {
     uint64_t population_bytes;  /* device bytes held by the population buffers */
     double   last_timed_ms;     /* device ms between the last timer_begin/timer_end pair */
     uint64_t last_timed_steps;  /* steps issued between them */
-    uint64_t last_timed_launches; /* step-kernel launches issued between them (large domains step in several
-                                   * launches of about 1 GB of traffic each, slabs in boundary + interior launches) */
+    uint64_t last_timed_launches; /* one-step kernel launches issued between them (large domains step in several
+                                   * launches of about 1 GB of traffic each, slabs in boundary + interior launches);
+                                   * the launches of the two-steps-per-pass path are counted below instead */
+    /* two steps per pass (lbm_opts.two_step): what one k_fused2 launch covers, and its share of the timed region */
+    uint64_t fused_cells;         /* cells one k_fused2 launch advances by two steps (0: the fused path is not in use) */
+    uint64_t rim_cells;           /* cells of the rim tiles, which take two one-step launches per pair instead */
+    uint64_t last_timed_fused_launches; /* k_fused2 launches between timer_begin and timer_end */
+    double   last_timed_fused_ms; /* their summed device time (HIP events around each launch) */
 } lbm_stats;
 
 /* lbm_solver::lbm_solver(int,int,int)  -- lbm_solver.cu:404-453.  opts may be NULL. */

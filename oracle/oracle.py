@@ -153,6 +153,10 @@ class Solver:
         """Current populations in the reference layout f[k*n + idx]."""
         return self.f.reshape(Q, self.n).copy()
 
+    def set_populations(self, f):
+        """Import populations in the reference layout (what cfd_amd.lbm.Solver.set_populations takes)."""
+        self.f[:] = np.asarray(f, np.float32).reshape(-1)
+
     def classification(self):
         cls = np.zeros((self.n, Q), np.uint8)
         sol = np.zeros(self.n, np.uint8)
