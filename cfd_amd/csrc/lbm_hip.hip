@@ -133,7 +133,23 @@ struct lbm_ctx {
 };
 
 static thread_local std::string g_create_error;
+
+// Scratch of lbm_read_velocity_strided_noalloc (include/lbm_abi.h): the staging area its sampling kernel
+// writes before the copy to the host, held in the code object instead of a hipMalloc per call.  Every
+// device the library runs on has its own copy at its own address; `scratch` itself is only the host-side
+// handle of the symbol, so host code uses the per-device address that lbm_create() looks up below.
+static __device__ __align__(256) unsigned char scratch[LBM_NOALLOC_MAX_SAMPLES * 4 * sizeof(float)];
 constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES] = {nullptr};
+// once per device, with that device current
+static hipError_t resolve_scratch(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (g_scratch_ptr[dev]) return hipSuccess;
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) g_scratch_ptr[dev] = ptr;
+    return e;
+}
 
 static int fail(lbm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -827,6 +843,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
             return cleanup(LBM_ERR_HIP);                                                           \
         }                                                                                          \
     } while (0)
+    CR(resolve_scratch(dev));
     if (o.boundary_stream && !o.stream) {
         fail(nullptr, LBM_ERR_INVALID, "lbm_create: lbm_opts.boundary_stream needs lbm_opts.stream (the caller orders the two streams)");
         return cleanup(LBM_ERR_INVALID);
@@ -1210,6 +1227,33 @@ int lbm_read_velocity_strided(lbm_ctx* c, int sx, int sy, int sz, float* u, size
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_read_velocity_strided: %s", hipGetErrorString(e));
+    return LBM_OK;
+}
+
+// The same sample without any allocation: the kernel writes into this device's copy of `scratch`.
+int lbm_read_velocity_strided_noalloc(lbm_ctx* c, int sx, int sy, int sz, float* u, size_t n) {
+    NEED(c);
+    if (sx < 1 || sy < 1 || sz < 1) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided_noalloc: strides must be positive");
+    const int nx = (c->g.W + sx - 1) / sx, ny = (c->g.H + sy - 1) / sy, nz = (c->g.fnz + sz - 1) / sz;
+    const size_t need = (size_t)nx * ny * nz;
+    if (!u || n != need) return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided_noalloc: need %zu x 4 floats (%d x %d x %d samples)", need, nx, ny, nz);
+    if (need > (size_t)LBM_NOALLOC_MAX_SAMPLES)
+        return fail(c, LBM_ERR_INVALID, "lbm_read_velocity_strided_noalloc: %zu samples exceed the fixed scratch of %d (LBM_NOALLOC_MAX_SAMPLES); "
+                    "use larger strides or lbm_read_velocity_strided", need, (int)LBM_NOALLOC_MAX_SAMPLES);
+    if (need == 0) return LBM_OK;
+    // rho/u are allocated on first use; this call may not do that
+    if (!c->rho || !c->u)
+        return fail(c, LBM_ERR_STATE, "lbm_read_velocity_strided_noalloc: the field buffers do not exist yet and this call allocates nothing: "
+                    "read a field once (lbm_read_velocity, lbm_device_fields, ...) after lbm_create / lbm_set_field_window");
+    float4* d = reinterpret_cast<float4*>(g_scratch_ptr[c->device]);
+    if (!d) return fail(c, LBM_ERR_STATE, "lbm_read_velocity_strided_noalloc: no scratch address for device %d", c->device);
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = fields_for_caller(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sample_velocity, grid1((long long)need), dim3(256), 0, c->stream, c->u, d, c->g.W, c->g.H, nx, ny, nz, sx, sy, sz);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(u, d, need * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LBM_OK;
 }
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lbm_read_velocity": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
     "lbm_read_velocity_strided": ([_ctx, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t], C.c_int),
+    "lbm_read_velocity_strided_noalloc": ([_ctx, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t], C.c_int),
     "lbm_read_speed": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_curl": ([_ctx, _fp, C.c_size_t], C.c_int),
     "lbm_read_populations": ([_ctx, _fp, C.c_size_t], C.c_int),
@@ -236,11 +237,12 @@ class Solver:
         self._chk(self._lib.lbm_read_velocity(self._ctx, _f(out), self.nf))
         return out
 
-    def velocity_strided(self, sx, sy, sz):
+    def velocity_strided(self, sx, sy, sz, noalloc=False):
         nz = self.nf // (self.W * self.H)
         shape = (-(-nz // max(sz, 1)), -(-self.H // max(sy, 1)), -(-self.W // max(sx, 1)))  # bad strides: the library rejects them
         out = np.empty(shape + (4,), np.float32)
-        self._chk(self._lib.lbm_read_velocity_strided(self._ctx, sx, sy, sz, _f(out), out.size // 4))
+        fn = self._lib.lbm_read_velocity_strided_noalloc if noalloc else self._lib.lbm_read_velocity_strided
+        self._chk(fn(self._ctx, sx, sy, sz, _f(out), out.size // 4))
         return out
 
     def speed(self):

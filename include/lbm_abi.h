@@ -170,6 +170,20 @@ int lbm_read_curl(lbm_ctx* ctx, float* curl, size_t n);
  *   lbm_read_speed: |u.xyz| per cell (cuda_math::length, cuda_math.cuh:142-145), n = W*H*nz. */
 int lbm_read_velocity_strided(lbm_ctx* ctx, int sx, int sy, int sz, float* u_xyzw, size_t n);
 int lbm_read_speed(lbm_ctx* ctx, float* speed, size_t n);
+/* lbm_read_velocity_strided for callers that cannot allocate: code under HIP graph capture, a renderer's
+ * per-frame loop (hipMalloc / hipFree synchronise the device), harnesses that forbid allocation.  No
+ * counterpart in the reference.  Same arguments and result; the sampling kernel's staging area is a fixed
+ * array inside the library's code object (LBM_NOALLOC_MAX_SAMPLES samples of 4 floats = 4 MiB, held by
+ * every GPU the library runs on until the process ends) instead of a hipMalloc per call, and the call
+ * issues no hipMalloc / hipFree:
+ *   - n > LBM_NOALLOC_MAX_SAMPLES is rejected with LBM_ERR_INVALID (use larger strides);
+ *   - rho/u are allocated on first use, which this call may not do: it returns LBM_ERR_STATE until some
+ *     field has been read once (lbm_read_velocity, lbm_device_fields, ...) after lbm_create or
+ *     lbm_set_field_window;
+ *   - all contexts on one GPU share that GPU's array: calls that overlap on one GPU (two host threads,
+ *     two contexts) race.  The kernel writes every sample it returns, so nothing is cleared between calls. */
+#define LBM_NOALLOC_MAX_SAMPLES (1 << 18)
+int lbm_read_velocity_strided_noalloc(lbm_ctx* ctx, int sx, int sy, int sz, float* u_xyzw, size_t n);
 /* Current populations in the reference layout f[k*n + idx] (d_f, lbm_solver.cuh:62). */
 int lbm_read_populations(lbm_ctx* ctx, float* f, size_t n_times_19);
 int lbm_write_populations(lbm_ctx* ctx, const float* f, size_t n_times_19);
