@@ -1,0 +1,145 @@
+"""Two steps per pass (cfd_amd/csrc/k_fused2.h, lbm_opts.two_step): lbm_step(ctx, n >= 3) on an A/B context
+advances blocks of plain-fluid tiles by TWO time steps in one kernel and takes the rim (walls, tiles near
+solids, ragged remainders) through two ordinary steps via a third buffer.  Every cell must come out
+bit-identical to the CPU oracle's single steps (lbm_solver.cu:242-402, 477-494) -- fields, populations and
+frozen solid cells -- for both presets, every compiled kernel variant, any z split, ragged sizes, obstacles,
+and across mask / parameter changes between calls."""
+import numpy as np
+import pytest
+
+from conftest import CUBE_OBJ
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["9,1,2", "12,1,1", "13,1,1", "9,0,2", "12,0,2"]
+
+
+def same(o, g, what=""):
+    np.testing.assert_array_equal(g.density(), o.density(), err_msg=what + " rho")
+    np.testing.assert_array_equal(g.velocity(), o.velocity(), err_msg=what + " u")
+    np.testing.assert_array_equal(g.populations(), o.populations(), err_msg=what + " f")
+
+
+def fused_in_use(lbm, g, may_decline=False):
+    """the fused path runs on the row-interleaved layout only; it may decline a domain of which it would
+    cover less than a quarter (one z chunk per column around obstacles)"""
+    import os
+    rows = os.environ.get("LBM_LAYOUT") == str(lbm.LAYOUT_ROWS)
+    used = g.stats()["fused_cells"] > 0
+    assert not used or rows
+    assert used or not rows or may_decline
+    return used
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("nsteps", [2, 3, 4, 11, 60])
+def test_fused_empty_box(oracle, lbm, preset, nsteps):
+    """no obstacle: walls, inlet / outlet (or cavity walls + lid) only; W ragged, last y tile short"""
+    W, H, D = 136, 27, 22
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    o.init(); g.init()
+    o.step(nsteps); g.step(nsteps)
+    same(o, g, f"preset {preset}, {nsteps} steps")
+    if nsteps >= 3:
+        fused_in_use(lbm, g)
+    else:
+        assert g.stats()["fused_cells"] == 0      # nothing prepared for calls that cannot fuse
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("zsplit", [0, 1, 3])
+def test_fused_variants_with_obstacles(oracle, lbm, variant, zsplit, monkeypatch):
+    monkeypatch.setenv("LBM_FUSED_VARIANT", variant)
+    monkeypatch.setenv("LBM_FUSED_ZSPLIT", str(zsplit))
+    W, H, D = 200, 40, 36
+    for preset in (0, 1):
+        o = oracle.Solver(W, H, D, preset)
+        g = lbm.Solver(W, H, D, preset)
+        for s in (o, g):
+            s.init()
+            s.add_solid(70, 0, 10, 20, 14, 9)        # on the floor, inside one tile column
+            s.add_solid(120, 20, 20, 12, 6, 6)       # floating, straddles a tile border in x
+            s.add_solid(W - 3, 30, 4, 3, 5, 5)       # in the outlet column
+        o.step(9); g.step(9)
+        same(o, g, f"variant {variant}, z split {zsplit}, preset {preset}")
+        st = g.stats()
+        if fused_in_use(lbm, g, may_decline=zsplit == 1):
+            assert 0 < st["fused_cells"] < W * H * D and st["rim_cells"] > 0
+            assert st["fused_cells"] + st["rim_cells"] <= W * H * D
+
+
+def test_fused_cube_64(oracle, lbm):
+    """BASELINE.json configs[0]: 64^3 channel around assets/cube.obj, 100 steps in calls of mixed length"""
+    o = oracle.Solver(64, 64, 64)
+    g = lbm.Solver(64, 64, 64)
+    for s in (o, g):
+        s.init(); s.load_mesh(CUBE_OBJ)
+    for n in (10, 1, 7, 2, 80):
+        o.step(n); g.step(n)
+        same(o, g, f"after a call of {n}")
+    assert abs(g.density().astype(np.float64).sum() - 274423.092220902) < 1e-6   # SURVEY.md Appendix A.2, N = 100
+    fused_in_use(lbm, g)
+
+
+def test_fused_mask_params_reset(oracle, lbm):
+    """eligibility and rim lists follow the mask; parameters are read per call; reset keeps the mask"""
+    W, H, D = 130, 30, 24
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D)
+    o.init(); g.init()
+    o.step(6); g.step(6)
+    c0 = g.stats()["fused_cells"]
+    for s in (o, g):
+        s.add_solid(40, 8, 6, 30, 9, 9)
+        s.set_params(inlet_velocity=0.05, omega_shear=1.7, omega_bulk=1.6)
+    o.step(7); g.step(7)
+    same(o, g, "after add_solid + set_params")
+    if fused_in_use(lbm, g):
+        assert g.stats()["fused_cells"] < c0
+    m = o.solid_mask().reshape(D, H, W).copy()
+    m[:, 8:17, 40:70] = 0                               # the box turns fluid again (frozen populations thaw)
+    m[10:14, 20:25, 100:110] = 255
+    o.set_solid(m); g.set_solid(m)
+    o.step(5); g.step(5)
+    same(o, g, "after set_solid")
+    o.init(); g.init()
+    o.step(4); g.step(4)
+    same(o, g, "after reset")
+    f = o.populations() * np.float32(1.01)
+    o.set_populations(f); g.set_populations(f)
+    o.step(5); g.step(5)
+    same(o, g, "after a population import")
+
+
+def test_fused_fields_on_demand_and_fused_moments(oracle, lbm):
+    """the last step of a call is a single step: rho/u on demand, rho/u fused into it, curl, field window"""
+    W, H, D = 72, 26, 20
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D)
+    for s in (o, g):
+        s.init(); s.add_solid(20, 0, 4, 9, 11, 9)
+    for n in (5, 6, 3):                                 # the second and third call write rho/u in their last step
+        o.step(n); g.step(n)
+        np.testing.assert_array_equal(g.density(), o.density())
+        np.testing.assert_array_equal(g.velocity(), o.velocity())
+    o.compute_curl()
+    np.testing.assert_array_equal(g.curl_field(), o.curl_field())
+    g.set_field_window(6, 4)
+    o.step(8); g.step(8)
+    np.testing.assert_array_equal(g.density().reshape(4, -1), o.density().reshape(D, -1)[6:10])
+
+
+def test_fused_equals_single_steps_256(lbm):
+    """BASELINE.json configs[1] at full size (256^3 cavity): 21 steps fused against 21 single steps"""
+    a = lbm.Solver(256, 256, 256, lbm.PRESET_CAVITY, two_step=lbm.TWO_STEP_OFF)
+    b = lbm.Solver(256, 256, 256, lbm.PRESET_CAVITY)
+    for s in (a, b):
+        s.init(); s.set_params(0.08, 1.8, 1.9); s.step(21)
+    assert a.stats()["fused_cells"] == 0
+    if fused_in_use(lbm, b):
+        assert b.stats()["fused_cells"] == 256 * 252 * 252
+    np.testing.assert_array_equal(a.density(), b.density())
+    np.testing.assert_array_equal(a.velocity(), b.velocity())
+    fa, fb = a.populations(), b.populations()
+    assert np.array_equal(fa, fb)
