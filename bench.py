@@ -1,27 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the D3Q19 hot path (BASELINE.json: MLUPS + % of HBM roofline).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
 
-A step is one fused stream-collide update of the whole domain (lbm_step(ctx, 1), 152 algorithmic
-bytes per cell: 19 fp32 populations read + written; rho/u are not written per step).
-Default (--config 1): BASELINE.json configs[1], the 256^3 lid-driven cavity, populations resident
-in HBM.  N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) cavity and
-exchanges the five face-crossing populations per face per step with its neighbours by RCCL
-send/recv (torch.distributed backend "nccl"), overlapped with the interior update.
---config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised
-car stand-in (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
+N = 1 runs in this process.  N > 1 without a torch.distributed environment starts N ranks of itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE anything
+touches the GPU and relays rank 0's JSON line; started under torch.distributed.run it is one of those ranks.
+
+A step is one D3Q19 stream-collide update of every cell (152 algorithmic bytes per cell: 19 fp32 populations
+read + written; rho/u are not written per step).  The timed region is ONE lbm_step(ctx, steps) call, so the
+library advances two steps per pass where it can (k_fused2, lbm_opts.two_step).  `steps` in the line is what
+was timed: the requested K, raised until the timed region lasts at least --min-seconds (0.5 s).
+
+Headline (--config 1): BASELINE.json configs[1], the 256^3 lid-driven cavity, populations resident in HBM.
+N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) cavity and exchanges the five
+face-crossing populations per face per step with its neighbours by RCCL send/recv (torch.distributed backend
+"nccl"), overlapped with the interior update.
+--config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised car stand-in
+(tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
 --config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
 --config 4: configs[4], AA in-place scheme sized to HBM (~3.4 G cells per GPU), weak scaling over z-slabs;
-`--config 4 --scheme slide` runs the same domain on the sliding in-place A/B scheme (8 % faster).
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the solver's stream;
-`cpu_baseline` times the CPU oracle (a port of the reference update: the reference has no CPU path)
-on a bounded sample of the same workload, on rank 0 at N = 1 only.
+`--config 4 --scheme slide` runs the same domain on the sliding in-place A/B scheme.
+
+Beside the headline the one JSON line carries
+  * `roofline`      the dominant kernel, timed live with HIP events on the solver's stream;
+  * `cpu_baseline`  the CPU oracle (a port of the reference update: the reference has no CPU path) on a bounded
+                    sample of the same workload, rank 0 at N = 1 only;
+  * `configs`       (N = 1) every other single-GPU configuration and output mode for a few steps each: configs[2],
+                    [3], [4] (AA as named and the sliding scheme), the 256^3 wind tunnel with the reference's
+                    boundary chain, and the reference-equivalent output modes (rho/u written every step: 172 B per
+                    cell; + curl every step: 192 B per cell; lbm_solver.cu:336-337,488);
+  * `strong_scaling` configs[3] split over the N ranks through the z-slab code path (at N = 1: one slab, RCCL
+                    ring to itself): MLUPS, ms per step, halo bytes per step, exposed communication time.
+Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,19 +48,84 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 152           # 19 populations x 4 B x (read + write)
 
-
 # The closed cavity is run at omega_shear = 1.8: with the reference's wind-tunnel default of 1.98 it is
 # under-resolved and blows up after about 700 steps (the CPU oracle does the same), which no benchmark
 # should time; at 1.8 / 1.9 and U = 0.08 it is stable (checked to 30 000 steps on the GPU).  The
 # wind-tunnel configurations keep the reference's defaults (lbm_solver.cuh:9-15).
 CAVITY_PARAMS = dict(inlet_velocity=0.08, omega_shear=1.8, omega_bulk=1.9)
+CAR = os.path.join(ROOT, "tests", "golden", "car_like.obj")
+
+# per-config workload: (per-GPU size, preset, scheme, obstacle, scaling)
+CONFIGS = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
+           2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
+           3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
+           4: ((1504, 1536, 1484), "wind_tunnel", "aa", None, "weak")}
+SCHEME_TEXT = {"ab": "A/B pull", "aa": "AA in-place", "slide": "sliding in-place A/B"}
 
 
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N > 1 typed as a plain command
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Start n ranks of this script under torch.distributed.run and relay rank 0's JSON line.  Runs before
+    this process has imported torch or touched the GPU (a process that has must never exec another)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    log("[bench] starting", n, "ranks:", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    else:
+        log("[bench] the ranks printed no JSON line")
+    return p.returncode if p.returncode else (0 if lines else 1)
+
+
+def dry_run_rank(args):
+    """--dry-run-launcher: the launcher's plumbing without a GPU (CPU test): rendezvous over gloo, a barrier, a
+    max-reduced timing, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "gpus_arg": args.gpus}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the only user of oracle/ in this file; runs after the timed GPU work)
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
     """Oracle (kind "port") on the host cores: the same workload, as many steps as fit the budget
     (at least 2); domains beyond 2^26 cells are cut to their first layers to bound memory and time."""
     from oracle import oracle as O
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    host_cores = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, host_cores)
     threads = max(1, min(threads, 16))
     os.environ["OMP_NUM_THREADS"] = str(threads)
     O.build()
@@ -62,9 +144,9 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
         steps += 1
     dt = time.perf_counter() - t0
     out = {"value": round(W * H * D * steps / dt / 1e6, 2), "unit": "MLUPS", "cores": threads,
-           "kind": "port",
+           "host_cores": host_cores, "kind": "port",
            "sample": f"{W}x{H}x{D} {'cavity' if preset else 'wind tunnel'}{' + car' if obj else ''}, {steps} steps of oracle/lbm_oracle.c (OpenMP over z, "
-                     f"{threads} threads, -O2 -ffp-contract=off), {dt:.1f} s"}
+                     f"{threads} threads of the host's {host_cores} logical CPUs, -O2 -ffp-contract=off), {dt:.1f} s"}
     # north_star's "single-threaded transliteration" figure beside it: the same code on one thread,
     # on a 128 x 128 x 64 corner of the workload (about 4 s)
     try:
@@ -88,6 +170,225 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# measurement helpers
+# ------------------------------------------------------------------------------------------------
+def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kernel=None):
+    """The dominant kernel of the timed region against the HBM roofline.  `achieved` = algorithmic bytes per
+    launch (bytes_per_cell x the cell updates one launch performs) / the launch's device time."""
+    fl, fms = stats["last_timed_fused_launches"], stats["last_timed_fused_ms"]
+    if fl and fms > 0:
+        # two steps per pass: one k_fused2 launch advances fused_cells cells by two steps (all of them fluid);
+        # its own device time comes from HIP events around every launch
+        launch_ms = fms / fl
+        updates = 2 * stats["fused_cells"]
+        name, launches_per_step = "k_fused2", fl / steps
+    else:
+        launches = max(1, stats["last_timed_launches"])
+        launch_ms = dev_ms / launches
+        updates = fluid * steps / launches
+        name, launches_per_step = kernel or "k_stream_collide", launches / steps
+    by = updates * bytes_per_cell
+    achieved = by / (launch_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": name,
+           "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches_per_step, 3),
+           "algorithmic_bytes_per_launch": round(by), "cell_updates_per_launch": round(updates),
+           "bytes_per_cell_update": bytes_per_cell}
+    if fl and fms > 0:
+        # the launch really moves about half of that (one read + one write per TWO updates, plus the tile halo);
+        # the counter figure is in profiles/ (rocprofv3 --pmc passes cannot run inside this process)
+        out["note"] = ("two updates per pass: algorithmic bytes are 152 B per cell update as SURVEY.md 8d defines them; "
+                       "HBM traffic per launch is about 0.55-0.6 x that (profiles/r02_*_pmc_traffic.txt)")
+        out["whole_step_frac"] = round(fluid * steps * bytes_per_cell / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["fused_share_of_cells"] = round(stats["fused_cells"] / max(1, stats["cells"]), 4)
+        out["fused_share_of_time"] = round(fms / dev_ms, 4)
+    return out
+
+
+def timed_steps(solver, step, steps_requested, min_seconds, fence, probe_steps=10):
+    """warm-up is done by the caller.  Times ONE step(n) call with n >= steps_requested chosen so that the region
+    lasts at least min_seconds; returns (n, wall seconds, device ms, stats)."""
+    n = steps_requested
+    if min_seconds > 0:
+        fence()
+        t0 = time.perf_counter()
+        step(probe_steps)
+        fence()
+        per = (time.perf_counter() - t0) / probe_steps
+        n = max(steps_requested, int(min_seconds / max(per, 1e-7)) + 1)
+    fence()
+    solver.timer_begin()
+    t0 = time.perf_counter()
+    step(n)
+    dev_ms = solver.timer_end()                 # HIP events on the solver's stream (synchronises it)
+    st = solver.stats()
+    fence()
+    return n, time.perf_counter() - t0, dev_ms, st
+
+
+def fluid_cells(solver, obstacle):
+    import numpy as np
+    return int((solver.solid_mask() == 0).sum()) if obstacle else solver.n
+
+
+def state_is_finite(solver):
+    import numpy as np
+    rho = solver.density()
+    return bool(np.isfinite(rho).all() and rho.max() < 10.0)
+
+
+def run_single(lbm, size, preset_name, scheme_name, obstacle, steps, warmup, min_seconds, device=0, slide_chunk=0,
+               field_window=None, mode="plain", two_step=True):
+    """One undecomposed solver on one GPU.  mode "plain": lbm_step(n); "rho_u": the reference's per-step output
+    (rho/u written by every step: step(1) + lbm_device_fields each step, 172 B per cell); "rho_u_curl": + the
+    curl pass every step (192 B per cell)."""
+    import ctypes as C
+    import torch
+    W, H, D = size
+    preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
+    scheme = {"ab": lbm.SCHEME_AB, "aa": lbm.SCHEME_AA, "slide": lbm.SCHEME_SLIDE}[scheme_name]
+    solver = lbm.Solver(W, H, D, preset=preset, device=device, scheme=scheme, slide_chunk=slide_chunk,
+                        two_step=lbm.TWO_STEP_AUTO if two_step else lbm.TWO_STEP_OFF)
+    try:
+        if field_window is not None:
+            solver.set_field_window(*field_window)
+        solver.init()
+        if preset == lbm.PRESET_CAVITY:
+            solver.set_params(**CAVITY_PARAMS)
+        if obstacle:
+            solver.load_mesh(CAR)
+        fp = C.POINTER(C.c_float)
+        rho, u, curl = fp(), fp(), fp()
+
+        def step(n):
+            if mode == "plain":
+                solver.step(n)
+                return
+            for _ in range(n):                   # the engine's frame loop: one step, then the fields on the device
+                solver.step(1)
+                solver._chk(solver._lib.lbm_device_fields(solver._ctx, C.byref(rho), C.byref(u),
+                                                          C.byref(curl) if mode == "rho_u_curl" else None, None))
+
+        def fence():
+            torch.cuda.synchronize()
+
+        step(warmup)
+        n, dt, dev_ms, st = timed_steps(solver, step, steps, min_seconds, fence)
+        if mode != "plain":
+            dev_ms = dt * 1e3                    # the per-step field passes run outside lbm_step's launches: wall time of the loop
+        fluid = fluid_cells(solver, obstacle)
+        bpc = {"plain": BYTES_PER_CELL, "rho_u": 172, "rho_u_curl": 192}[mode]
+        res = {"cells": W * H * D, "fluid_cells": fluid, "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
+               "mlups": round(W * H * D * n / dt / 1e6, 1), "state_finite": state_is_finite(solver),
+               "population_bytes": st["population_bytes"], "bytes_per_cell": bpc}
+        if mode == "plain":
+            res["roofline"] = roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")
+        else:
+            ach = fluid * bpc * n / dt / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "k_stream_collide (rho/u fused)" + (" + k_curl" if mode == "rho_u_curl" else ""),
+                               "note": "whole frame loop (wall clock): one step per call, fields left on the device"}
+        return res
+    finally:
+        solver.close()
+
+
+def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmup, min_seconds, world, rank, local_rank, dist,
+              want_exposed=True):
+    """This rank's z-slab of the domain through the split step + RCCL halo exchange (cfd_amd/slab.py).  `dist` is an
+    initialised torch.distributed (world 1: a ring to itself)."""
+    import torch
+    from cfd_amd import slab
+    W, H, Dg = size_global
+    D = Dg // world
+    preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
+    scheme = {"ab": lbm.SCHEME_AB, "aa": lbm.SCHEME_AA, "slide": lbm.SCHEME_SLIDE}[scheme_name]
+    # two streams: boundary layers + RCCL on a side stream beside the interior update (3-4 % faster
+    # than one stream whenever a rank has a neighbour, tools/rccl_self_probe.py)
+    eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme, two_streams=True)
+    solver = eng.solver
+    try:
+        if scheme != lbm.SCHEME_AB:
+            # the in-place schemes write rho/u of the field window in every split step: keep it small
+            solver.set_field_window(0, min(4, D))
+        drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
+        solver.init()
+        if preset == lbm.PRESET_CAVITY:
+            solver.set_params(**CAVITY_PARAMS)
+        if obstacle:
+            solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
+        drv.exchange_mask()
+        drv.exchange_populations()
+        drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
+
+        def fence():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        drv.step(warmup)
+        n, dt, dev_ms, st = timed_steps(solver, drv.step, steps, min_seconds, fence)
+        tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt, dev_ms = float(tmax[0]), float(tmax[1])
+        fluid = fluid_cells(solver, obstacle)
+        t = torch.tensor([fluid], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slab with the most fluid sets the step time
+        fluid = int(t[0])
+        finite = torch.tensor([1 if state_is_finite(solver) else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+        res = {"cells_per_gpu": W * H * D, "fluid_cells_per_gpu": fluid, "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
+               "mlups": round(W * H * D * world * n / dt / 1e6, 1), "state_finite": bool(int(finite[0])),
+               "rccl_ranks": world, "slab_layers": D,
+               "halo_bytes_per_step_per_gpu": 4 * eng.message_floats() * ((drv.up is not None) + (drv.down is not None)),
+               "roofline": roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")}
+        if want_exposed:
+            # the same slab without any exchange: lbm_step on the slab context (the ghost layers go stale, which
+            # changes no kernel's work); exposed communication = split step with exchange - this
+            fence()
+            solver.timer_begin()
+            solver.step(min(n, 50))
+            ms_plain = solver.timer_end() / min(n, 50)
+            tp = torch.tensor([ms_plain], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            res["ms_per_step_no_exchange"] = round(float(tp[0]), 5)
+            res["exposed_comm_ms_per_step"] = round(max(0.0, dt / n * 1e3 - float(tp[0])), 5)
+        return res
+    finally:
+        solver.close()
+
+
+def sweep_single_gpu(lbm, device, budget):
+    """Every other single-GPU configuration / output mode for a few steps each (N = 1 only)."""
+    out = []
+    plan = [
+        ("256^3 wind tunnel, reference boundary chain, A/B", None, (256, 256, 256), "wind_tunnel", "ab", None, {}),
+        ("256^3 wind tunnel, rho/u written every step (reference-equivalent output, 172 B/cell)", None, (256, 256, 256), "wind_tunnel", "ab", None, {"mode": "rho_u"}),
+        ("256^3 wind tunnel, rho/u + curl every step (reference-equivalent output, 192 B/cell)", None, (256, 256, 256), "wind_tunnel", "ab", None, {"mode": "rho_u_curl"}),
+        ("256^3 cavity, one step per pass (two_step off)", 1, (256, 256, 256), "cavity", "ab", None, {"two_step": False}),
+        ("512x256x256 wind tunnel + car, A/B", 2, (512, 256, 256), "wind_tunnel", "ab", "car", {}),
+        ("512x256x256 wind tunnel + car, sliding in-place", 2, (512, 256, 256), "wind_tunnel", "slide", "car", {"field_window": (0, 4)}),
+        ("1024x512x512 wind tunnel + car, one GPU, A/B", 3, (1024, 512, 512), "wind_tunnel", "ab", "car", {"field_window": (0, 4)}),
+        ("1504x1536x1484 wind tunnel (267 GB), AA in-place as BASELINE.json names it", 4, (1504, 1536, 1484), "wind_tunnel", "aa", None, {"field_window": (0, 4)}),
+        ("1504x1536x1484 wind tunnel (267 GB), sliding in-place", 4, (1504, 1536, 1484), "wind_tunnel", "slide", None, {"field_window": (0, 4)}),
+    ]
+    for text, idx, size, preset, scheme, obstacle, kw in plan:
+        t0 = time.perf_counter()
+        entry = {"workload": text, "baseline_config": idx, "scheme": SCHEME_TEXT[scheme]}
+        try:
+            big = size[0] * size[1] * size[2] > (1 << 30)
+            entry.update(run_single(lbm, size, preset, scheme, obstacle, steps=4 if big else 20, warmup=2 if big else 5,
+                                    min_seconds=budget, device=device, **kw))
+        except Exception as e:                     # one configuration failing (e.g. no room for 267 GB) must not cost the line
+            entry["error"] = f"{type(e).__name__}: {e}"
+        entry["bench_seconds"] = round(time.perf_counter() - t0, 1)
+        log("[bench] sweep:", json.dumps(entry))
+        out.append(entry)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,10 +399,21 @@ def main():
     ap.add_argument("--preset", choices=["cavity", "wind_tunnel"], default=None)
     ap.add_argument("--scheme", choices=["ab", "aa", "slide"], default=None)
     ap.add_argument("--slide-chunk", type=int, default=0, help="--scheme slide: layers per launch (0 = library default)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="raise the timed step count until the timed region lasts this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="N = 1: skip the `configs` array (the other single-GPU configurations)")
+    ap.add_argument("--no-strong-scaling", action="store_true", help="skip the `strong_scaling` record (configs[3] over the N ranks)")
+    ap.add_argument("--one-step", action="store_true", help="turn the two-steps-per-pass path off (lbm_opts.two_step)")
     ap.add_argument("--rehearse-slab", action="store_true",
-                    help="N = 1 only: run the z-slab code path of N > 1 (split step, RCCL ring to itself)")
+                    help="N = 1 only: run the headline through the z-slab code path of N > 1 (split step, RCCL ring to itself)")
+    ap.add_argument("--dry-run-launcher", action="store_true", help="CPU test of the N > 1 launcher: gloo rendezvous only")
     args = ap.parse_args()
+
+    in_dist = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_dist:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.dry_run_launcher:
+        sys.exit(dry_run_rank(args))
 
     # stdout carries exactly ONE line, the JSON: RCCL (version banner at communicator creation) and other
     # libraries print to fd 1 as well, so everything but that line goes to stderr
@@ -115,19 +427,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    # per-config workload: (per-GPU size, preset, scheme, obstacle, scaling)
-    cfg = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
-           2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
-           3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
-           4: ((1504, 1536, 1484), "wind_tunnel", "aa", None, "weak")}[args.config]
-    size, preset_name, scheme_name, obstacle, scaling = cfg
+    size, preset_name, scheme_name, obstacle, scaling = CONFIGS[args.config]
     if args.size:
         size = tuple(args.size)
     preset_name = args.preset or preset_name
@@ -140,126 +444,74 @@ def main():
     else:
         Dg = D * world
     preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
-    scheme = {"ab": lbm.SCHEME_AB, "aa": lbm.SCHEME_AA, "slide": lbm.SCHEME_SLIDE}[scheme_name]
-    scheme_text = {"ab": "A/B pull", "aa": "AA in-place", "slide": "sliding in-place A/B"}[scheme_name]
-    car = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
     dist = None
-    if world > 1 or args.rehearse_slab:
+    need_dist = world > 1 or args.rehearse_slab or not args.no_strong_scaling
+    if need_dist:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from cfd_amd import slab
-        # two streams: boundary layers + RCCL on a side stream beside the interior update (3-4 % faster
-        # than one stream whenever a rank has a neighbour, tools/rccl_self_probe.py)
-        eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme, two_streams=True)
-        solver = eng.solver
-        if scheme != lbm.SCHEME_AB:
-            # the in-place schemes write rho/u of the field window in every split step: keep it small
-            solver.set_field_window(0, min(4, D))
-        drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
-        solver.init()
-        if preset == lbm.PRESET_CAVITY:
-            solver.set_params(**CAVITY_PARAMS)
-        if obstacle:
-            solver.load_mesh(car)   # device voxeliser: every slab casts the rays of its own layers
-        drv.exchange_mask()
-        drv.exchange_populations()
-        drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
-        step = drv.step
+
+    slab_path = world > 1 or args.rehearse_slab
+    if slab_path:
+        head = run_slabs(lbm, (W, H, Dg), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
+                         world, rank, local_rank, dist, want_exposed=True)
+        cells, fluid = head["cells_per_gpu"], head["fluid_cells_per_gpu"]
     else:
-        solver = lbm.Solver(W, H, D, preset=preset, device=local_rank, scheme=scheme, slide_chunk=args.slide_chunk)
-        if args.config == 4:
-            solver.set_field_window(0, 4)   # sized to HBM: no room for whole-domain rho/u (20 B/cell)
-        solver.init()
-        if preset == lbm.PRESET_CAVITY:
-            solver.set_params(**CAVITY_PARAMS)
-        if obstacle:
-            solver.load_mesh(car)
-        step = solver.step
+        head = run_single(lbm, (W, H, D), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
+                          device=local_rank, slide_chunk=args.slide_chunk,
+                          field_window=(0, 4) if args.config == 4 else None, two_step=not args.one_step)
+        cells, fluid = head["cells"], head["fluid_cells"]
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step(args.warmup)
-    fence()
-    solver.timer_begin()
-    t0 = time.perf_counter()
-    step(args.steps)
-    dev_ms = solver.timer_end()                 # HIP events on the solver's stream
-    launches = max(1, solver.stats()["last_timed_launches"])   # a step is cut into launches of ~1 GB of traffic
-    fence()
-    dt = time.perf_counter() - t0
-
-    if dist is not None:
-        tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt, dev_ms = float(tmax[0]), float(tmax[1])
-
-    # the timed state must be a flow, not a blown-up one: look at the density the run ended with
-    import numpy as np
-    rho_end = solver.density()
-    state_finite = bool(np.isfinite(rho_end).all() and rho_end.max() < 10.0)
-    del rho_end
-
-    cells = W * H * D
-    # solid cells are skipped by the kernel (no loads, no stores): the roofline counts fluid cells only
-    fluid = cells
-    if obstacle:
-        fluid = int((solver.solid_mask() == 0).sum())
-        if dist is not None:
-            t = torch.tensor([fluid], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the slab with the most fluid sets the step time
-            fluid = int(t[0])
-    mlups_total = cells * world * args.steps / dt / 1e6
-    ms_per_step = dt / args.steps * 1e3
-    # dominant kernel: k_stream_collide; one launch per step at N=1 (three at N>1: 2 boundary
-    # layers + interior); achieved = algorithmic bytes per step / device time per step
-    dev_ms_per_step = dev_ms / args.steps
-    launch_ms = dev_ms / launches
-    bytes_per_launch = fluid * BYTES_PER_CELL * args.steps / launches
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{W}x{H}x{D}_{preset_name}_{scheme_name}")
-        except Exception:
-            traffic = None
-
+    out = None
     if rank == 0:
         out = {
             "metric": "MLUPS (D3Q19 fused stream-collide, whole job)",
-            "value": round(mlups_total, 1), "unit": "MLUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "value": head["mlups"], "unit": "MLUPS",
+            "n_gpus": world, "steps": head["steps"], "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, "
-                                   f"{scheme_text}, "
+            "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, {SCHEME_TEXT[scheme_name]}, "
                                    f"{'voxelised car stand-in, ' if obstacle else ''}"
-                                   f"{'z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo' if world > 1 else 'one GPU'}"
+                                   f"{'z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo' if slab_path else 'one GPU'}"
                                    f" (BASELINE.json configs[{args.config}])",
                        "per_gpu_cells": cells, "per_gpu_fluid_cells": fluid, "bytes_per_cell": BYTES_PER_CELL,
                        "layout": "row-interleaved [z][y][k][x], rows padded to 128 B",
                        "params": CAVITY_PARAMS if preset == lbm.PRESET_CAVITY else "reference defaults (U 0.08, omega 1.98 / 1.90)",
-                       "moments_per_step": False},
-            "mlups_per_gpu": round(mlups_total / world, 1), "state_finite": state_finite,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide",
-                         "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches / args.steps, 3),
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                         "fluid_cells_per_launch": round(fluid * args.steps / launches)},
+                       "moments_per_step": False,
+                       "two_steps_per_pass": head["roofline"]["kernel"] == "k_fused2"},
+            "mlups_per_gpu": round(head["mlups"] / world, 1), "state_finite": head["state_finite"],
+            "roofline": head["roofline"],
         }
+        if slab_path:
+            out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "slab_layers", "halo_bytes_per_step_per_gpu",
+                                                     "ms_per_step_no_exchange", "exposed_comm_ms_per_step") if k in head}
+
+    # configs[3] over the N ranks (strong scaling), through the same slab path at every N
+    if not args.no_strong_scaling and not (args.config == 3 and slab_path):
+        Ws, Hs, Ds = CONFIGS[3][0]
+        if Ds % world == 0:
+            try:
+                ss = run_slabs(lbm, (Ws, Hs, Ds), "wind_tunnel", "ab", "car", steps=20, warmup=5, min_seconds=args.min_seconds,
+                               world=world, rank=rank, local_rank=local_rank, dist=dist, want_exposed=True)
+                ss["workload"] = f"wind_tunnel {Ws}x{Hs}x{Ds} + voxelised car stand-in, A/B, z-slabs {world} x {Ds // world} layers (BASELINE.json configs[3])"
+            except Exception as e:
+                ss = {"error": f"{type(e).__name__}: {e}"}
+            if out is not None:
+                out["strong_scaling"] = ss
+                log("[bench] strong scaling:", json.dumps(ss))
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        if world == 1 and not args.no_sweep:
+            out["configs"] = sweep_single_gpu(lbm, local_rank, min(args.min_seconds, 0.5))
         if world == 1 and not args.no_cpu_baseline:
-            solver.close()
-            out["cpu_baseline"] = cpu_baseline(W, H, D, preset, car if obstacle else None)
+            out["cpu_baseline"] = cpu_baseline(W, H, D, preset, CAR if obstacle else None)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -148,6 +148,28 @@ LBM_HD void collide_cell(const float* f, const Moments& m, float omega_shear, fl
 
     out[0] = w0r * (1.0f - c15) + c0 * d000;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Directions k and inv(k) run through the same five operations on (+a, -a): written on two-float vectors
+    // so that they issue as packed instructions (v_pk_add_f32 / v_pk_mul_f32, two results per issue slot).
+    // Each component is the same IEEE operation sequence as the scalar form below: 1 + a, + b, - c15, * w rho,
+    // + fneq, and 1 - a = 1 + (-a) exactly.
+    typedef float lbm_f2 __attribute__((ext_vector_type(2)));
+#define LBM_PAIR(KP, KM, CU, WR, CW, NEQ)                         \
+    {                                                             \
+        const float cu = (CU);                                    \
+        const float a = 3.0f * cu;                                \
+        const float b = 4.5f * cu * cu;                           \
+        const float fneq = (CW) * (NEQ);                          \
+        lbm_f2 t = {a, -a};                                       \
+        t = 1.0f + t;                                             \
+        t = t + b;                                                \
+        t = t - c15;                                              \
+        t = (WR) * t;                                             \
+        t = t + fneq;                                             \
+        out[KP] = t.x;                                            \
+        out[KM] = t.y;                                            \
+    }
+#else
 #define LBM_PAIR(KP, KM, CU, WR, CW, NEQ)                         \
     {                                                             \
         const float cu = (CU);                                    \
@@ -157,6 +179,7 @@ LBM_HD void collide_cell(const float* f, const Moments& m, float omega_shear, fl
         out[KP] = (WR) * (1.0f + a + b - c15) + fneq;             \
         out[KM] = (WR) * (1.0f - a + b - c15) + fneq;             \
     }
+#endif
     LBM_PAIR(1, 2, ux, w1r, c1, d100)
     LBM_PAIR(3, 4, uy, w1r, c1, d010)
     LBM_PAIR(5, 6, uz, w1r, c1, d001)

@@ -173,7 +173,7 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     // outlet adjustments included, non-negative)
     const char* base_in = reinterpret_cast<const char*>(fin + (long long)(zs - 3) * g.layer);
     char* base_out = reinterpret_cast<char*>(fout + (long long)(zs - 3) * g.layer);
-    const unsigned layer_b = (unsigned)(g.layer * 4);
+    const unsigned layer_b = (unsigned)(g.layer * 4), plane_b = (unsigned)(g.plane * 4);
     const unsigned cell_b = (unsigned)(((long long)(active ? y : y0) * g.row + (active ? x : x0)) * 4);
     auto off_of = [&](int L) { return (unsigned)(L - (zs - 3)) * layer_b + cell_b; };
 
@@ -221,7 +221,8 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned offo = off_of(L - 1);
 #pragma unroll
-                for (int k = 0; k < Q; k++) __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (long long)k * g.plane * 4 + offo));
+                for (int k = 0; k < Q; k++)   // one base, 32-bit offsets: population k sits k planes further on
+                    __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (offo + (unsigned)k * plane_b)));
             } else {
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

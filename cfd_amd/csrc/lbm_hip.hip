@@ -124,6 +124,9 @@ struct lbm_ctx {
     size_t rim_n[2] = {0, 0}, rim_cap[2] = {0, 0};          // entries, padded to a multiple of 4
     long long fused_cells = 0;     // cells one k_fused2 launch updates (twice each)
     long long rim_cells = 0;       // cells of the rim tiles (second list)
+    hipStream_t stream_rim = nullptr;   // library-owned side stream: the rim's two small launches run beside k_fused2
+    hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
+    bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
     std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
     size_t f2_ev_used = 0;
     bool timing = false;
@@ -612,10 +615,24 @@ static int fused_prepare(lbm_ctx* c) {
     return LBM_OK;
 }
 
-// two time steps: t (f[cur]) -> t+2 (f[1-cur])
-static int fused_pair(lbm_ctx* c) {
+// two time steps: t (f[cur]) -> t+2 (f[1-cur]).  `first`: the first pair of a batch.
+// The rim's two launches touch no cell the fused kernel touches, so they run on a side stream beside it; both
+// streams meet again before the next pair (which reads everything this one wrote) and after the last one.
+static int fused_pair(lbm_ctx* c, bool first) {
     const float* in = c->f[c->cur];
     float* out = c->f[1 - c->cur];
+    hipStream_t rim_stream = c->stream;
+    if (c->f2_overlap) {
+        if (!c->stream_rim) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_main, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_rim, hipEventDisableTiming));
+        }
+        rim_stream = c->stream_rim;
+        if (!first) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));   // the previous pair's rim
+        HIPCHK(c, hipEventRecord(c->ev_f2_main, c->stream));                       // ... and its fused launch, and all before
+        HIPCHK(c, hipStreamWaitEvent(rim_stream, c->ev_f2_main, 0));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {  // device time of the dominant kernel alone, for the roofline figure
         if (c->f2_ev_used + 2 > c->f2_ev.size() && c->f2_ev.size() < 1024) {
@@ -629,10 +646,16 @@ static int fused_pair(lbm_ctx* c) {
     if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "k_fused2 launch failed: %s", hipGetErrorString(e));
     if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
     c->fused_launches++;
-    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[0], c->rim_n[0]);
-    if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[1], c->rim_n[1]);
+    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[0], c->rim_n[0]);
+    if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[1], c->rim_n[1]);
     if (rc) return rc;
+    if (c->f2_overlap) HIPCHK(c, hipEventRecord(c->ev_f2_rim, rim_stream));
     c->cur = 1 - c->cur;
+    return LBM_OK;
+}
+// after the last pair of a batch: later work on the context's stream sees the rim's results
+static int fused_join(lbm_ctx* c) {
+    if (c->f2_overlap && c->stream_rim) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
     return LBM_OK;
 }
 
@@ -821,6 +844,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->fused_on = o.two_step != LBM_TWO_STEP_OFF;
     if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
+    if (const char* t = getenv("LBM_FUSED_OVERLAP")) c->f2_overlap = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_VARIANT")) {
         int ty = 0, st = 0, nb = 0;
         bool known = false;
@@ -906,6 +930,9 @@ int lbm_destroy(lbm_ctx* c) {
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
     hipFree(c->ft); hipFree(c->f2_elig); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
     for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
+    if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
+    if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);
+    if (c->ev_f2_rim) hipEventDestroy(c->ev_f2_rim);
     hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -1105,11 +1132,14 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     if (nsteps >= 3 && fused_applies(c)) {
         rc = fused_prepare(c);
         if (rc) return rc;
-        if (c->fused_usable)
+        if (c->fused_usable) {
             for (; s + 2 < nsteps; s += 2) {
-                rc = fused_pair(c);
+                rc = fused_pair(c, s == 0);
                 if (rc) return rc;
             }
+            rc = fused_join(c);
+            if (rc) return rc;
+        }
     }
     for (; s < nsteps; s++) {
         rc = launch_ab_layers(c, 1, c->g.D, fuse && s == nsteps - 1);
