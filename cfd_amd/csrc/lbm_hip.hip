@@ -118,8 +118,8 @@ struct lbm_ctx {
     int f2_zsplit = 0;             // LBM_FUSED_ZSPLIT: z chunks per tile column (0 = chosen by fused_prepare)
     FusedGrid fg{};
     float* ft = nullptr;           // third population buffer: holds time t+1 on the rim between its two steps
-    unsigned char* f2_elig = nullptr;   // one byte per workgroup of k_fused2: 1 = its haloed block is plain fluid
-    size_t f2_elig_cap = 0;
+    unsigned* f2_blocks = nullptr;      // the eligible blocks (bx | by << 12 | bz << 24), one workgroup of k_fused2 each
+    size_t f2_blocks_cap = 0;
     unsigned long long* rim_list[2] = {nullptr, nullptr};   // [0]: tiles that need t+1 (rim + its neighbours), [1]: the rim
     size_t rim_n[2] = {0, 0}, rim_cap[2] = {0, 0};          // entries, padded to a multiple of 4
     long long fused_cells = 0;     // cells one k_fused2 launch updates (twice each)
@@ -127,6 +127,7 @@ struct lbm_ctx {
     hipStream_t stream_rim = nullptr;   // library-owned side stream: the rim's two small launches run beside k_fused2
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
     bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
+    bool f2_rim_pending = false;   // the side stream holds rim launches the context's stream has not waited for yet
     std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
     size_t f2_ev_used = 0;
     bool timing = false;
@@ -454,7 +455,7 @@ static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout
         if (e != hipSuccess) return e;
         attr_set[c->device] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(c->fg.nbx, c->fg.nby, c->fg.nbz), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_elig,
+    hipLaunchKernelGGL(kern, dim3(c->fg.nblocks), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
                        c->g, c->p, c->fg);
     return hipGetLastError();
 }
@@ -496,13 +497,14 @@ static int fused_prepare(lbm_ctx* c) {
     const int TY = c->f2_ty;
     // rows [2, H-2) and layers z in [2, D-2) can take the fused path: the haloed blocks must stay off the wall
     // rows / layers, whose tiles are flagged as boundary tiles
-    if (g.H < 6 || g.D < 6 || g.Wt >= 65536 || g.H >= (1 << 24) || g.D + 2 >= (1 << 24)) return LBM_OK;
+    if (g.H < 6 || g.D < 6 || g.Wt > 4096 || g.H >= (1 << 24) || g.D + 2 >= (1 << 24)) return LBM_OK;
     const long long layer_b = g.layer * 4;
     if (layer_b >= (1ll << 30)) return LBM_OK;                      // 32-bit byte offsets inside a z chunk (k_fused2.h)
     FusedGrid fg;
     fg.nbx = g.Wt;
     fg.y_first = 2; fg.y_end = g.H - 2;
     fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
+    if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 + 12 + 8 bits
     fg.zl_first = 3; fg.zl_end = g.D - 1;
     const int nz = fg.zl_end - fg.zl_first;
     const int max_chunk = (int)std::min<long long>(nz, ((1ll << 32) - 1) / layer_b - 5);
@@ -521,7 +523,7 @@ static int fused_prepare(lbm_ctx* c) {
         const double eff = (double)wgs / (double)((wgs + ncu - 1) / ncu * ncu) * zc / (zc + 2.0);
         if (eff > best_eff + 1e-9) { best_eff = eff; best_nbz = nbz; }
     }
-    if (c->f2_zsplit > 0) {
+    if (c->f2_zsplit > 0 && c->f2_zsplit <= 256) {
         const int zc = (nz + c->f2_zsplit - 1) / c->f2_zsplit;
         if (zc <= max_chunk) best_nbz = (nz + zc - 1) / zc;
     }
@@ -560,6 +562,13 @@ static int fused_prepare(lbm_ctx* c) {
             }
         }
     if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
+    std::vector<unsigned> blocks;
+    for (size_t b = 0; b < nblocks; b++)
+        if (elig[b]) {
+            const unsigned bx = (unsigned)(b % fg.nbx), by = (unsigned)((b / fg.nbx) % fg.nby), bz = (unsigned)(b / ((size_t)fg.nbx * fg.nby));
+            blocks.push_back(bx | (by << 12) | (bz << 24));
+        }
+    fg.nblocks = (int)blocks.size();
 
     // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
     // t+1 values from the 26 neighbouring tiles, so the first rim step covers the rim dilated by one tile
@@ -601,7 +610,7 @@ static int fused_prepare(lbm_ctx* c) {
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream, c->f[c->cur], c->ft, c->mask, c->g);
         HIPCHK(c, hipGetLastError());
     }
-    int rc = fused_upload(c, (void**)&c->f2_elig, &c->f2_elig_cap, elig.data(), elig.size());
+    int rc = fused_upload(c, (void**)&c->f2_blocks, &c->f2_blocks_cap, blocks.data(), blocks.size() * sizeof(unsigned));
     for (int i = 0; i < 2 && !rc; i++) {
         rc = fused_upload(c, (void**)&c->rim_list[i], &c->rim_cap[i], list[i].data(), list[i].size() * sizeof(unsigned long long));
         c->rim_n[i] = list[i].size();
@@ -622,14 +631,17 @@ static int fused_pair(lbm_ctx* c, bool first) {
     const float* in = c->f[c->cur];
     float* out = c->f[1 - c->cur];
     hipStream_t rim_stream = c->stream;
-    if (c->f2_overlap) {
+    // worth it when the rim is a good part of the domain (obstacles: +3 % at 512x256x256 + car); around an empty
+    // box the two small launches cost the same beside the fused kernel as behind it
+    const bool overlap = c->f2_overlap && c->rim_cells * 100 > cells(c) * 15;
+    if (overlap) {
         if (!c->stream_rim) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_main, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_rim, hipEventDisableTiming));
         }
         rim_stream = c->stream_rim;
-        if (!first) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));   // the previous pair's rim
+        if (!first && c->f2_rim_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));   // the previous pair's rim
         HIPCHK(c, hipEventRecord(c->ev_f2_main, c->stream));                       // ... and its fused launch, and all before
         HIPCHK(c, hipStreamWaitEvent(rim_stream, c->ev_f2_main, 0));
     }
@@ -649,13 +661,15 @@ static int fused_pair(lbm_ctx* c, bool first) {
     int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[0], c->rim_n[0]);
     if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[1], c->rim_n[1]);
     if (rc) return rc;
-    if (c->f2_overlap) HIPCHK(c, hipEventRecord(c->ev_f2_rim, rim_stream));
+    if (overlap) HIPCHK(c, hipEventRecord(c->ev_f2_rim, rim_stream));
+    c->f2_rim_pending = overlap;
     c->cur = 1 - c->cur;
     return LBM_OK;
 }
 // after the last pair of a batch: later work on the context's stream sees the rim's results
 static int fused_join(lbm_ctx* c) {
-    if (c->f2_overlap && c->stream_rim) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
+    if (c->f2_rim_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
+    c->f2_rim_pending = false;
     return LBM_OK;
 }
 
@@ -928,7 +942,7 @@ int lbm_destroy(lbm_ctx* c) {
     if (!c->f1_in_alloc0) hipFree(c->f[1]);
     hipFree(c->mask); hipFree(c->flags);
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
-    hipFree(c->ft); hipFree(c->f2_elig); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
+    hipFree(c->ft); hipFree(c->f2_blocks); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
     for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
     if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
     if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);
@@ -1023,6 +1037,31 @@ int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
     (void)hipFree(dense);
     if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_set_solid_u8: %s", hipGetErrorString(e));
     c->mask_dirty = true;
+    return LBM_OK;
+}
+
+// the mask from a dense uint8 array that already lives on the device (cuda_buffer::copy_from_device)
+int lbm_set_solid_u8_device(lbm_ctx* c, const uint8_t* d_mask, size_t n) {
+    NEED(c);
+    if (!d_mask) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8_device: mask is null");
+    if (n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8_device: expected %lld cells, got %zu", cells(c), n);
+    int rc = before_mask_change(c);
+    if (rc) return rc;
+    const long long nwords = (long long)c->g.D * c->g.H * c->g.Wm;
+    hipLaunchKernelGGL(k_pack_mask, grid1(nwords), dim3(256), 0, c->stream, d_mask, c->mask, c->g);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its array at once (cudaMemcpy semantics)
+    c->mask_dirty = true;
+    return LBM_OK;
+}
+
+// cudaMemcpy(..., cudaMemcpyDeviceToDevice) for hosts that do not link the HIP runtime themselves
+int lbm_device_copy(lbm_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+    NEED(c);
+    if (!d_dst || !d_src) return fail(c, LBM_ERR_INVALID, "lbm_device_copy: null pointer");
+    if (bytes == 0) return LBM_OK;
+    HIPCHK(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LBM_OK;
 }
 

@@ -52,7 +52,7 @@ class hip_buffer {
    public:
     enum class field { density, velocity, solid, curl };
     hip_buffer() = default;
-    hip_buffer(lbm_ctx* ctx, field f, size_t size) : m_ctx(ctx), m_field(f), m_size(size) {}
+    hip_buffer(lbm_ctx* ctx, field f, size_t size) : m_ctx(ctx), m_field(f), m_size(size), m_full(size) {}
     hip_buffer(const hip_buffer&) = delete;  // reference quirk Q8 (shallow copy) not reproduced
     hip_buffer& operator=(const hip_buffer&) = delete;
     hip_buffer(hip_buffer&&) = default;
@@ -60,21 +60,46 @@ class hip_buffer {
 
     // cuda_buffer.cuh:79-84: blocking D2H copy of `size` elements, silently skipped if size > m_size
     void copy_to_host(T* host_data, size_t size) {
-        if (!m_ctx || size > m_size) return;
-        if (size == m_size) {
+        if (!m_ctx || size > m_size || size > m_full) return;
+        if (size == m_full) {
             read_all(host_data);
         } else {
-            std::vector<T> tmp(m_size);
+            std::vector<T> tmp(m_full);
             read_all(tmp.data());
             std::memcpy(host_data, tmp.data(), size * sizeof(T));
         }
     }
+    // cuda_buffer.cuh:93-98: blocking device-to-device copy of `size` elements out of the field (what a
+    // renderer does with get_velocity() / get_solid_mask()); silently skipped if size > m_size
+    void copy_to_device(T* device_ptr, size_t size) {
+        if (!m_ctx || size > m_size || size > m_full) return;
+        const T* src = get_data();
+        if (src) LBM_CHECK(m_ctx, lbm_device_copy(m_ctx, device_ptr, src, size * sizeof(T)));
+    }
+    // cuda_buffer.cuh:86-91; like copy_from_host only the whole solid mask is an input here
+    void copy_from_device(const T* device_ptr, size_t size) {
+        if (!m_ctx || size > m_size) return;
+        if (m_field != field::solid || size != m_full) {
+            std::fprintf(stderr, "[error] copy_from_device: only the whole solid mask can be written\n");
+            return;
+        }
+        LBM_CHECK(m_ctx, lbm_set_solid_u8_device(m_ctx, reinterpret_cast<const uint8_t*>(device_ptr), size));
+    }
+    // cuda_buffer.cuh:56-64: a released buffer answers every later call with a no-op / null.  The fields belong
+    // to the solver (external, non-owning memory in the reference's terms, cuda_buffer.cuh:28-29), so nothing is freed.
+    void release() {
+        m_ctx = nullptr;
+        m_size = 0;
+        m_full = 0;
+    }
+    // cuda_buffer.cuh:116: changes the bound the copy calls check against, not the field
+    void set_size(const size_t size) { m_size = size; }
     // cuda_buffer.cuh:72-77 as the solver uses it (lbm_solver.cu:555: the whole solid mask from the
     // host).  Density / velocity / curl are results of step() here, not inputs: writes to them are
     // rejected with a log line, where the reference would overwrite values its next step recomputes.
     void copy_from_host(const T* host_data, size_t size) {
         if (!m_ctx || size > m_size) return;
-        if (m_field != field::solid || size != m_size) {
+        if (m_field != field::solid || size != m_full) {
             std::fprintf(stderr, "[error] copy_from_host: only the whole solid mask can be written\n");
             return;
         }
@@ -87,7 +112,7 @@ class hip_buffer {
             std::fprintf(stderr, "[error] memset: only the solid mask can be written\n");
             return;
         }
-        std::vector<uint8_t> v(m_size, static_cast<uint8_t>(value));
+        std::vector<uint8_t> v(m_full, static_cast<uint8_t>(value));
         LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, v.data(), v.size()));
     }
     // device pointer in the reference wire format, up to date and synchronised
@@ -113,15 +138,16 @@ class hip_buffer {
    private:
     void read_all(T* dst) {
         switch (m_field) {
-            case field::density: LBM_CHECK(m_ctx, lbm_read_density(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
-            case field::velocity: LBM_CHECK(m_ctx, lbm_read_velocity(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
-            case field::curl: LBM_CHECK(m_ctx, lbm_read_curl(m_ctx, reinterpret_cast<float*>(dst), m_size)); break;
-            case field::solid: LBM_CHECK(m_ctx, lbm_read_solid_u8(m_ctx, reinterpret_cast<uint8_t*>(dst), m_size)); break;
+            case field::density: LBM_CHECK(m_ctx, lbm_read_density(m_ctx, reinterpret_cast<float*>(dst), m_full)); break;
+            case field::velocity: LBM_CHECK(m_ctx, lbm_read_velocity(m_ctx, reinterpret_cast<float*>(dst), m_full)); break;
+            case field::curl: LBM_CHECK(m_ctx, lbm_read_curl(m_ctx, reinterpret_cast<float*>(dst), m_full)); break;
+            case field::solid: LBM_CHECK(m_ctx, lbm_read_solid_u8(m_ctx, reinterpret_cast<uint8_t*>(dst), m_full)); break;
         }
     }
     lbm_ctx* m_ctx = nullptr;
     field m_field = field::density;
-    size_t m_size = 0;
+    size_t m_size = 0;   // the bound copy calls check against (set_size changes it)
+    size_t m_full = 0;   // elements of the field itself
 };
 
 class lbm_solver {

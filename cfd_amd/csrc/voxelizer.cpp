@@ -72,6 +72,70 @@ void Mesh::set_triangles(const float* xyz9, size_t ntris) {
     }
 }
 
+namespace {
+
+// Faces with more than four vertices.  The reference's OBJ loader cuts ears (tiny_obj_loader.h:1751-1973), and
+// which triangles come out decides the mask wherever a face is concave, so the same search is run here: project
+// on the two axes of the first real corner's dominant normal component, walk a cursor round the remaining
+// vertices, take a triple as an ear when it turns the way the loader's area term says and holds no other
+// remaining vertex, drop its middle vertex, stop after a whole round without an ear.
+template <class Emit>
+void clip_ears(const std::vector<Vec3>& verts, const std::vector<long>& face, Emit&& emit) {
+    const size_t n = face.size();
+    auto coord = [](const Vec3& p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); };
+    int ax0 = 1, ax1 = 2;
+    for (size_t k = 0; k < n; k++) {
+        const Vec3 &a = verts[face[k]], &b = verts[face[(k + 1) % n]], &c = verts[face[(k + 2) % n]];
+        const Vec3 e0 = sub(b, a), e1 = sub(c, b);
+        const float nx = std::fabs(e0.y * e1.z - e0.z * e1.y);
+        const float ny = std::fabs(e0.z * e1.x - e0.x * e1.z);
+        const float nz = std::fabs(e0.x * e1.y - e0.y * e1.x);
+        const float eps = std::numeric_limits<float>::epsilon();
+        if (nx > eps || ny > eps || nz > eps) {
+            const bool x_dominates = nx > ny && nx > nz;
+            if (!x_dominates) {
+                ax0 = 0;
+                if (nz > nx && nz > ny) ax1 = 1;
+            }
+            break;
+        }
+    }
+    // is (tx, ty) inside the triangle (px, py)?  Crossing-number test over the three edges.
+    auto inside = [](const float* px, const float* py, float tx, float ty) {
+        bool in = false;
+        for (int i = 0, j = 2; i < 3; j = i++)
+            if ((py[i] > ty) != (py[j] > ty) && tx < (px[j] - px[i]) * (ty - py[i]) / (py[j] - py[i]) + px[i]) in = !in;
+        return in;
+    };
+    std::vector<long> left(face);
+    size_t cursor = 0, budget = n, seen = n;
+    while (left.size() > 3 && budget > 0) {
+        const size_t m = left.size();
+        if (cursor >= m) cursor -= m;
+        if (seen != m) { seen = m; budget = m; } else { budget--; }
+        long id[3];
+        float px[3], py[3];
+        for (int k = 0; k < 3; k++) {
+            id[k] = left[(cursor + k) % m];
+            px[k] = coord(verts[id[k]], ax0);
+            py[k] = coord(verts[id[k]], ax1);
+        }
+        const float turn = (px[1] - px[0]) * (py[2] - py[1]) - (py[1] - py[0]) * (px[2] - px[1]);
+        const float area = (px[0] * py[1] - py[0] * px[1]) * 0.5f;
+        bool ear = !(turn * area < 0.0f);
+        for (size_t o = 3; ear && o < m; o++) {
+            const Vec3& q = verts[left[(cursor + o) % m]];
+            if (inside(px, py, coord(q, ax0), coord(q, ax1))) ear = false;
+        }
+        if (!ear) { cursor++; continue; }
+        emit(verts[id[0]], verts[id[1]], verts[id[2]]);
+        left.erase(left.begin() + static_cast<long>((cursor + 1) % m));
+    }
+    if (left.size() == 3) emit(verts[left[0]], verts[left[1]], verts[left[2]]);
+}
+
+}  // namespace
+
 bool Mesh::load_obj(const std::string& path) {
     std::ifstream in(path);
     if (!in) return false;
@@ -119,9 +183,7 @@ bool Mesh::load_obj(const std::string& path) {
                 if (len_ac < len_bd) { emit(a, b, c); emit(a, c, d); }
                 else                 { emit(a, b, d); emit(b, c, d); }
             } else {
-                // n-gons: fan (the vendored loader ear-clips; same hit set for convex faces)
-                for (size_t i = 1; i + 1 < ids.size(); i++)
-                    emit(verts[ids[0]], verts[ids[i]], verts[ids[i + 1]]);
+                clip_ears(verts, ids, emit);
             }
         }
     }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "lbm_get_params": ([_ctx, _fp, _fp, _fp], C.c_int),
     "lbm_add_solid_rect": ([_ctx] + [C.c_int] * 6, C.c_int),
     "lbm_set_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
+    "lbm_set_solid_u8_device": ([_ctx, C.c_void_p, C.c_size_t], C.c_int),
+    "lbm_device_copy": ([_ctx, C.c_void_p, C.c_void_p, C.c_size_t], C.c_int),
     "lbm_load_mesh": ([_ctx, C.c_char_p], C.c_int),
     "lbm_step": ([_ctx, C.c_int], C.c_int),
     "lbm_compute_curl": ([_ctx], C.c_int),

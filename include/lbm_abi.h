@@ -140,6 +140,13 @@ int lbm_add_solid_rect(lbm_ctx* ctx, int x, int y, int z, int w, int h, int d);
 /* d_solid.copy_from_host -- cuda_buffer.cuh:72-77 as used at lbm_solver.cu:555: replaces the
  * whole mask (nonzero = solid).  For a slab context `n` is the slab's own W*H*depth cells. */
 int lbm_set_solid_u8(lbm_ctx* ctx, const uint8_t* mask, size_t n);
+/* cuda_buffer<unsigned char>::copy_from_device on d_solid -- cuda_buffer.cuh:86-91: the whole mask from a dense
+ * uint8 array in DEVICE memory (nonzero = solid); synchronises like the reference's cudaMemcpy. */
+int lbm_set_solid_u8_device(lbm_ctx* ctx, const uint8_t* d_mask, size_t n);
+/* cuda_buffer<T>::copy_to_device -- cuda_buffer.cuh:93-98: a blocking device-to-device copy on the context's
+ * device and stream, for hosts that do not link the HIP runtime themselves (the source is a pointer obtained
+ * from lbm_device_fields). */
+int lbm_device_copy(lbm_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* lbm_solver::load_mesh -- lbm_solver.cu:521-556 + MeshVoxelizer (mesh_voxelizer.cpp:20-246):
  * OBJ -> rotate_y(-90) -> 0.8 auto-scale -> +X ray-cast voxelisation -> y=0 plane solid ->
  * whole mask replaced.  A missing file returns LBM_ERR_IO after installing the floor-only mask,

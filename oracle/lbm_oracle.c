@@ -367,8 +367,8 @@ void orc_add_solid_rect(unsigned char* solid, int W, int H, int D,
  * behaviour of the vendored tinyobjloader that matters here: `v` and `f` records, 1-based and
  * negative indices, `a/b/c` index triplets, triangles kept, quads split by the shorter
  * diagonal with ties going to [0,1,3],[1,2,3] (tiny_obj_loader.h:1520-1616).  Faces with more
- * than four vertices are fan-triangulated (tinyobj ear-clips them; identical for convex
- * polygons up to triangle order, which does not change hit sets; documented exclusion).
+ * than four vertices are ear-clipped the way the loader's built-in triangulation does it
+ * (tiny_obj_loader.h:1751-1973; the reference does not define TINYOBJLOADER_USE_MAPBOX_EARCUT).
  * ========================================================================================= */
 typedef struct { float x, y, z; } v3;
 typedef struct { v3 a, b, c; } tri_t;
@@ -415,6 +415,79 @@ static void mesh_push(orc_mesh* m, v3 a, v3 b, v3 c) {
     m->bmin = v3min(m->bmin, a); m->bmax = v3max(m->bmax, a);
     m->bmin = v3min(m->bmin, b); m->bmax = v3max(m->bmax, b);
     m->bmin = v3min(m->bmin, c); m->bmax = v3max(m->bmax, c);
+}
+
+/* point in polygon, tiny_obj_loader.h:1449-1461 (W. R. Franklin's pnpoly) */
+static int orc_pnpoly(int nvert, const float* vertx, const float* verty, float testx, float testy) {
+    int i, j, c = 0;
+    for (i = 0, j = nvert - 1; i < nvert; j = i++) {
+        if (((verty[i] > testy) != (verty[j] > testy)) &&
+            (testx < (vertx[j] - vertx[i]) * (testy - verty[i]) / (verty[j] - verty[i]) + vertx[i]))
+            c = !c;
+    }
+    return c;
+}
+static float v3axis(v3 p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
+
+/* Faces with more than four vertices: tiny_obj_loader.h:1751-1973.  The polygon is projected on the two axes
+ * picked from its first non-degenerate corner (:1756-1808); then ears are cut off: starting at `guess`, a
+ * vertex triple is an ear when its turn has the sign of the "area" term (:1859-1877, the loader's own
+ * formula) and no other remaining vertex lies inside it (:1879-1911); the ear is emitted, its middle vertex
+ * removed (:1913-1943), and the search gives up after one fruitless round (:1816-1840).  The last three
+ * vertices make the final triangle (:1948-1973). */
+static void orc_ear_clip(orc_mesh* m, const v3* verts, const long* face, int n) {
+    int axes[2] = {1, 2};
+    for (int k = 0; k < n; k++) {
+        v3 p0 = verts[face[k % n]], p1 = verts[face[(k + 1) % n]], p2 = verts[face[(k + 2) % n]];
+        float e0x = p1.x - p0.x, e0y = p1.y - p0.y, e0z = p1.z - p0.z;
+        float e1x = p2.x - p1.x, e1y = p2.y - p1.y, e1z = p2.z - p1.z;
+        float cx = fabsf(e0y * e1z - e0z * e1y);
+        float cy = fabsf(e0z * e1x - e0x * e1z);
+        float cz = fabsf(e0x * e1y - e0y * e1x);
+        const float eps = FLT_EPSILON;
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) {
+                axes[0] = 0;
+                if (cz > cx && cz > cy) axes[1] = 1;
+            }
+            break;
+        }
+    }
+    long rem[64];
+    int nrem = n;
+    for (int i = 0; i < n; i++) rem[i] = face[i];
+    size_t guess = 0;
+    size_t remaining_iterations = (size_t)n, previous_remaining = (size_t)n;
+    while (nrem > 3 && remaining_iterations > 0) {
+        size_t np = (size_t)nrem;
+        if (guess >= np) guess -= np;
+        if (previous_remaining != np) { previous_remaining = np; remaining_iterations = np; }
+        else remaining_iterations--;
+        long ind[3];
+        float vx[3], vy[3];
+        for (int k = 0; k < 3; k++) {
+            ind[k] = rem[(guess + (size_t)k) % np];
+            vx[k] = v3axis(verts[ind[k]], axes[0]);
+            vy[k] = v3axis(verts[ind[k]], axes[1]);
+        }
+        float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0];
+        float e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+        float cross = e0x * e1y - e0y * e1x;
+        float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+        if (cross * area < 0.0f) { guess += 1; continue; }
+        int overlap = 0;
+        for (size_t other = 3; other < np; other++) {
+            size_t idx = (guess + other) % np;
+            float tx = v3axis(verts[rem[idx]], axes[0]), ty = v3axis(verts[rem[idx]], axes[1]);
+            if (orc_pnpoly(3, vx, vy, tx, ty)) { overlap = 1; break; }
+        }
+        if (overlap) { guess += 1; continue; }
+        mesh_push(m, verts[ind[0]], verts[ind[1]], verts[ind[2]]);
+        size_t removed = (guess + 1) % np;
+        while (removed + 1 < np) { rem[removed] = rem[removed + 1]; removed++; }
+        nrem--;
+    }
+    if (nrem == 3) mesh_push(m, verts[rem[0]], verts[rem[1]], verts[rem[2]]);
 }
 
 /* returns 0 on success (mesh_voxelizer.cpp:20-86) */
@@ -466,8 +539,7 @@ int orc_mesh_load_obj(orc_mesh* m, const char* path) {
                 if (s02 < s13) { mesh_push(m, p0, p1, p2); mesh_push(m, p0, p2, p3); }
                 else           { mesh_push(m, p0, p1, p3); mesh_push(m, p1, p2, p3); }
             } else {
-                for (int i = 1; i + 1 < cnt; i++)
-                    mesh_push(m, verts[ids[0]], verts[ids[i]], verts[ids[i + 1]]);
+                orc_ear_clip(m, verts, ids, cnt);
             }
         }
     }

@@ -193,6 +193,22 @@ def collide_cell(f19, omega_shear, omega_bulk):
     return out, ru
 
 
+def mesh_triangles(path):
+    """The triangles the OBJ reader produces (quad split / ear clipping applied), as an (n, 9) float32 array."""
+    L = lib()
+    m = L.orc_mesh_new()
+    try:
+        if L.orc_mesh_load_obj(m, os.fsencode(path)) != 0:
+            raise FileNotFoundError(path)
+        n = L.orc_mesh_ntris(m)
+        out = np.zeros((n, 9), np.float32)
+        if n:
+            L.orc_mesh_get_tris(m, _fp(out))
+        return out
+    finally:
+        L.orc_mesh_free(m)
+
+
 def voxelize_obj(path, W, H, D, floor_plane=True):
     mask = np.zeros(W * H * D, np.uint8)
     sc = C.c_float(0)

@@ -103,10 +103,56 @@ static void MaskWritesAndSchemes() {
     EXPECT(rho[0] == rho[2]);
 }
 
+// the rest of cuda_buffer's surface (cuda_buffer.cuh:56-64, 86-98, 116): device-to-device copies out of a field
+// and into the mask, set_size, release.  The "renderer side" device arrays here are other solvers' fields.
+static void DeviceCopiesSetSizeRelease() {
+    const int W = 80, H = 20, D = 12;
+    const size_t n = static_cast<size_t>(W) * H * D;
+    lbm_solver a(W, H, D), b(W, H, D);
+    a.init(); b.init();
+    a.add_solid({10, 0, 2, 9, 7, 5});
+    for (int i = 0; i < 5; i++) { a.step(); b.step(); }
+    // b's mask := a's mask, device to device; afterwards both must evolve alike once b restarts
+    b.get_solid_mask().copy_from_device(a.get_solid_mask().get_data(), n);
+    std::vector<unsigned char> ma(n), mb(n, 9);
+    a.get_solid_mask().copy_to_host(ma.data(), n);
+    b.get_solid_mask().copy_to_host(mb.data(), n);
+    EXPECT(ma == mb);
+    a.reset(); b.reset();
+    for (int i = 0; i < 6; i++) { a.step(); b.step(); }
+    // a's velocity -> b's velocity array on the device (the copy a renderer makes), read back through b
+    b.step();                                                   // b is one step ahead: the fields differ
+    std::vector<cuda_math::vec4> ua(n), ub(n);
+    a.get_velocity().copy_to_host(ua.data(), n);
+    b.get_velocity().copy_to_host(ub.data(), n);
+    EXPECT(std::memcmp(ua.data(), ub.data(), n * sizeof(cuda_math::vec4)) != 0);
+    cuda_math::vec4* dst = b.get_velocity().get_data();
+    a.get_velocity().copy_to_device(dst, n);
+    b.get_velocity().copy_to_host(ub.data(), n);               // b's device array now holds a's field
+    EXPECT(std::memcmp(ua.data(), ub.data(), n * sizeof(cuda_math::vec4)) == 0);
+    // oversized device copies are skipped silently like the host ones
+    a.get_density().copy_to_device(b.get_density().get_data(), n + 1);
+    // set_size lowers the bound the copies check
+    std::vector<float> r(n, -1.0f);
+    a.get_density().set_size(10);
+    a.get_density().copy_to_host(r.data(), n);                  // n > 10: skipped
+    EXPECT(r[0] == -1.0f);
+    a.get_density().copy_to_host(r.data(), 10);
+    EXPECT(r[0] > 0.0f && r[9] > 0.0f && r[10] == -1.0f);
+    a.get_density().set_size(n);
+    // a released view answers nothing any more
+    a.get_curl().release();
+    EXPECT(a.get_curl().size() == 0);
+    std::vector<float> c(n, -2.0f);
+    a.get_curl().copy_to_host(c.data(), n);
+    EXPECT(c[0] == -2.0f);
+}
+
 int main(int argc, char** argv) {
     Initialization();
     ResetAndStep(argc > 1 ? argv[1] : "tests/golden/cube.obj");
     MaskWritesAndSchemes();
+    DeviceCopiesSetSizeRelease();
     std::printf(failures ? "%d FAILED\n" : "all C++ lbm_solver tests passed\n", failures);
     return failures ? 1 : 0;
 }

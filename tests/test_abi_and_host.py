@@ -107,3 +107,37 @@ def test_voxeliser_random_soup_and_obj_syntax(oracle, lbm, tmp_path):
     assert rco != 0 and rcp == -4
     np.testing.assert_array_equal(mp, mo)               # floor only (lbm_solver.cu:522-524, 549-553)
     assert (mp.reshape(8, 8, 16)[:, 0, :] == 255).all() and int((mp > 0).sum()) == 16 * 8
+
+
+L_PRISM = os.path.join(GOLDEN, "l_prism.obj")
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (96, 40, 48), (50, 70, 33)])
+def test_concave_ngon_faces_are_ear_clipped(oracle, lbm, dims):
+    """Faces with more than four vertices: the reference's loader cuts ears (tiny_obj_loader.h:1751-1973).
+    tests/golden/l_prism.obj has concave 7-gon caps whose first corner does not see the whole polygon (a fan
+    from it would cover the notch) and whose first three vertices are collinear.  Product == oracle bit for
+    bit, and the voxelised solid is the L: filled arms, empty notch."""
+    W, H, D = dims
+    mo, so, rco = oracle.voxelize_obj(L_PRISM, W, H, D)
+    mp, sp, rcp = lbm.host_voxelize_obj(L_PRISM, W, H, D)
+    assert rco == 0 and rcp == 0 and np.float32(so) == np.float32(sp)
+    np.testing.assert_array_equal(mp, mo)
+    # both loaders turn the 7-gon caps into 5 triangles each: 10 + 6 quads x 2
+    tris = oracle.mesh_triangles(L_PRISM)
+    assert len(tris) == 22
+    # geometry after load_mesh: rotate_y(-90) maps (x, y, z) -> (-z, y, x); the mesh is centred in x and z and
+    # sits on y = 0.  The L occupies z' = x in [0, 40] for y < 10 and z' in [0, 10] for y in [10, 30).
+    m = mp.reshape(D, H, W) > 0
+    s = np.float32(sp)
+    zc = D / 2.0
+    z_of = lambda xo: int(np.floor(zc + (xo - 20.0) * s))          # original x -> grid z
+    x_mid = W // 2
+    y_low, y_high = max(1, int(5 * s)), int(20 * s)
+    assert m[z_of(30.0), y_low, x_mid] and m[z_of(5.0), y_low, x_mid]          # the bar, both ends
+    assert m[z_of(5.0), y_high, x_mid]                                          # the tall arm
+    assert not m[z_of(30.0), y_high, x_mid]                                     # the notch stays empty
+    # solid volume ~ the L's area x depth (in voxels), far from the 1.5 x a fan over the notch would give
+    vol = m[:, 1:, :].sum()
+    expect = (40 * 10 + 10 * 20) * 30 * float(s) ** 3
+    assert 0.75 * expect < vol < 1.2 * expect, (vol, expect)     # voxel rounding: up to a voxel per face on the coarse grids

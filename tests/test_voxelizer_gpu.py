@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 CAR_OBJ = os.path.join(GOLDEN, "car_like.obj")
 
 
-@pytest.mark.parametrize("obj", [CUBE_OBJ, CAR_OBJ])
+@pytest.mark.parametrize("obj", [CUBE_OBJ, CAR_OBJ, os.path.join(GOLDEN, "l_prism.obj")])   # l_prism: concave 7-gon faces (ear clipping)
 @pytest.mark.parametrize("dims", [(64, 64, 64), (400, 100, 100), (128, 64, 64), (70, 33, 17), (200, 300, 40)])
 def test_device_mask_equals_host_and_oracle(oracle, lbm, obj, dims):
     W, H, D = dims
