@@ -26,11 +26,11 @@
 // operands in the same order as two single steps, so results are bit-identical (tests/test_fused_gpu.py).
 
 struct FusedGrid {
-    int nbx, nby, nbz;      // blocks: 64-cell tiles in x, TY-row tiles in y, chunks in z
-    int nblocks;            // eligible blocks = workgroups of a launch
+    int nbx, nby, nbz;      // 64-cell tiles in x, TY-row tiles in y, pieces an unobstructed tile column is cut into in z
+    int nblocks;            // blocks = workgroups of a launch
     int y_first, y_end;     // rows [y_first, y_end) take the fused path (y_first >= 2, y_end <= H - 2)
-    int zl_first, zl_end;   // local layers (ghost offset included) [zl_first, zl_end): zl_first >= 3, zl_end <= D - 1
-    int zchunk;             // layers per z chunk
+    int zl_first, zl_end;   // local layers (ghost offset included) the blocks lie in: [3, D - 1)
+    int zchunk;             // most layers a block takes
 };
 
 constexpr int F2_LCOLS = 66;   // 64 cells + one halo column each side
@@ -147,32 +147,34 @@ struct F2<PRESET, -1> {
 // NBUF 2: two exchange buffers, one barrier per layer; 1: one buffer, two barriers per layer.
 template <int PRESET, int TY, int STAGE, int NBUF>
 __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
-                                                          const unsigned* __restrict__ blocks, Geo g, Params p,
+                                                          const unsigned long long* __restrict__ blocks, Geo g, Params p,
                                                           FusedGrid fg) {
     constexpr int ROWS = TY + 2;
     constexpr int PLANE = ROWS * F2_LCOLS;
     constexpr int EXCH = 16 * PLANE;
     extern __shared__ float lds[];
-    // One workgroup per ELIGIBLE block (the host compacts them into `blocks`, ordered z chunk / y tile / x tile;
-    // the rim path owns every other block).  The hardware deals workgroups to the 8 XCDs round-robin in launch
+    // One workgroup per block of the host's list (fused_prepare() in lbm_hip.hip: a 64 x TY tile and a run of
+    // layers whose haloed neighbourhood is plain fluid, ordered layer range / y tile / x tile; the rim path owns
+    // every other cell).  The hardware deals workgroups to the 8 XCDs round-robin in launch
     // order, and each XCD has its own L2.  Neighbouring tiles read each other's edge lines (the halo rows and
     // columns, the second 128-byte line of an x-shifted load), so every XCD takes ONE contiguous range of the
     // list: the lines two tiles share are then fetched from HBM once instead of once per L2, and every XCD
     // still gets the same number of blocks whatever the obstacles leave eligible.
-    int bx, by, bz;
+    int bx, by, zs, ze;                                          // second step: local layers [zs, ze)
     {
         const unsigned total = gridDim.x, launch = blockIdx.x;
         const unsigned xcd = launch & 7u, nth = launch >> 3, q = total >> 3, r = total & 7u;
-        const unsigned e = blocks[F2_XCD_REMAP ? xcd * q + min(xcd, r) + nth : launch];
+        const unsigned long long e = blocks[F2_XCD_REMAP ? xcd * q + min(xcd, r) + nth : launch];
         bx = (int)(e & 0xfffu);
         by = (int)((e >> 12) & 0xfffu);
-        bz = (int)(e >> 24);
+        zs = (int)((e >> 24) & 0xfffffu);
+        ze = zs + (int)(e >> 44);
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int role = f2_role<TY>(wave);
     const int x0 = bx * 64, y0 = fg.y_first + by * TY;
     const int tyn = min(TY, fg.y_end - y0);                     // rows of this tile that exist (the last tile may be short)
-    const int zs = fg.zl_first + bz * fg.zchunk, ze = min(zs + fg.zchunk, fg.zl_end);   // second step: layers [zs, ze)
+
     int x, r;
     bool active;
     if (role < ROWS) { r = role; x = x0 + lane; active = true; }

@@ -22,7 +22,7 @@ struct Geo {
 //   LBM_LAYOUT_ROWS    [z][y][k][x] : plane = Wp,  row = 19*Wp,      layer = rows*row
 // In the row-interleaved form the 19 runs of one (y,z) row are one contiguous 19*Wp*4-byte chunk:
 // a step writes whole chunks and reads 1-3 KB pieces of nine neighbouring chunks, which streams
-// 6-7 % faster from HBM than 19+19 far-apart planes (profiles/r01_tuning.md, tools/membench5/6).
+// 6-7 % faster from HBM than 19+19 far-apart planes (profiles/r01_tuning.md, tools/probes/membench5/6).
 
 struct Params {
     float U, omega_shear, omega_bulk;
@@ -49,7 +49,7 @@ __device__ __forceinline__ bool solid_at(const Geo& g, const unsigned long long*
 // Populations whose A/B fast-path load is non-temporal when TUNE bit 0 is set (bit k = population k).
 // Default: the ten x-shifted populations keep the default policy -- their misaligned loads touch a
 // second 128-byte line that the neighbouring wave needs too; nt would drop it after one use
-// (+2 % at 256^3, tools/tune_bench.py).
+// (+2 % at 256^3, tools/probes/tune_bench.py).
 #ifndef LBM_NT_SET
 #define LBM_NT_SET 0x78079u   // cx == 0: k = 0, 3, 4, 5, 6, 15, 16, 17, 18
 #endif

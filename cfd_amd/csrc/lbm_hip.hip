@@ -114,11 +114,11 @@ struct lbm_ctx {
     bool fused_on = false;         // lbm_opts.two_step / LBM_FUSED
     bool fused_ready = false;      // eligibility map and rim lists match the current mask
     bool fused_usable = false;     // ... and enough of the domain takes the fused path for it to pay
-    int f2_ty = 9, f2_stage = 1, f2_nbuf = 2;   // kernel variant (LBM_FUSED_VARIANT="TY,STAGE,NBUF")
+    int f2_ty = 12, f2_stage = 1, f2_nbuf = 1;  // kernel variant: measured best of the compiled ones (profiles/r02_tuning.md) (LBM_FUSED_VARIANT="TY,STAGE,NBUF")
     int f2_zsplit = 0;             // LBM_FUSED_ZSPLIT: z chunks per tile column (0 = chosen by fused_prepare)
     FusedGrid fg{};
     float* ft = nullptr;           // third population buffer: holds time t+1 on the rim between its two steps
-    unsigned* f2_blocks = nullptr;      // the eligible blocks (bx | by << 12 | bz << 24), one workgroup of k_fused2 each
+    unsigned long long* f2_blocks = nullptr;   // the blocks (x tile | y tile << 12 | first layer << 24 | layers << 44), one workgroup of k_fused2 each
     size_t f2_blocks_cap = 0;
     unsigned long long* rim_list[2] = {nullptr, nullptr};   // [0]: tiles that need t+1 (rim + its neighbours), [1]: the rim
     size_t rim_n[2] = {0, 0}, rim_cap[2] = {0, 0};          // entries, padded to a multiple of 4
@@ -500,19 +500,40 @@ static int fused_prepare(lbm_ctx* c) {
     if (g.H < 6 || g.D < 6 || g.Wt > 4096 || g.H >= (1 << 24) || g.D + 2 >= (1 << 24)) return LBM_OK;
     const long long layer_b = g.layer * 4;
     if (layer_b >= (1ll << 30)) return LBM_OK;                      // 32-bit byte offsets inside a z chunk (k_fused2.h)
-    FusedGrid fg;
-    fg.nbx = g.Wt;
-    fg.y_first = 2; fg.y_end = g.H - 2;
-    fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
-    if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 + 12 + 8 bits
-    fg.zl_first = 3; fg.zl_end = g.D - 1;
-    const int nz = fg.zl_end - fg.zl_first;
-    const int max_chunk = (int)std::min<long long>(nz, ((1ll << 32) - 1) / layer_b - 5);
+    const int max_chunk = (int)std::min<long long>(g.D, ((1ll << 32) - 1) / layer_b - 5);
     if (max_chunk < 1) return LBM_OK;
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    // z chunks per tile column: whole rounds of one workgroup per CU, against the two redundant first-step
-    // layers every chunk starts with
+
+    // tile flags -> host
+    const long long ntiles = (long long)g.D * g.H * g.Wt;
+    std::vector<unsigned char> fl((size_t)ntiles);
+    HIPCHK(c, hipMemcpyAsync(fl.data(), c->flags, (size_t)ntiles, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto tile = [&](int xs, int y, int z) -> size_t { return ((size_t)z * g.H + y) * g.Wt + xs; };   // z = zl - 1
+
+    // The rows the tiles start from: the first row whose lower neighbour is (mostly) plain fluid.  A closed box
+    // gives y_first = 2 (row 0 is the wall row, row 1 the lower halo row); the wind tunnel's solid floor plane
+    // (lbm_solver.cu:549-553) flags row 1 as well and moves the tiles up by one.
+    auto row_clean = [&](int y) {
+        long long clean = 0;
+        for (int z = 1; z + 1 < g.D; z++)
+            for (int xs = 0; xs < g.Wt; xs++) clean += fl[tile(xs, y, z)] == 0;
+        return clean * 2 >= (long long)(g.D - 2) * g.Wt;
+    };
+    FusedGrid fg;
+    fg.nbx = g.Wt;
+    fg.y_first = 2;
+    while (fg.y_first < std::min(g.H / 4, 8) && !row_clean(fg.y_first - 1)) fg.y_first++;
+    fg.y_end = g.H - 2;
+    while (fg.y_end > g.H - std::min(g.H / 4, 8) && !row_clean(fg.y_end)) fg.y_end--;
+    if (fg.y_end - fg.y_first < 1) return LBM_OK;
+    fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
+    if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 bits for the y tile
+    fg.zl_first = 3; fg.zl_end = g.D - 1;                           // widest possible range of second-step layers
+    const int nz = fg.zl_end - fg.zl_first;
+    // Layers per block for an unobstructed tile column: whole rounds of one workgroup per CU, against the two
+    // redundant first-step layers every block starts with.
     int best_nbz = 0;
     double best_eff = -1.0;
     for (int nbz = 1; nbz <= std::min(nz, 256); nbz++) {
@@ -523,51 +544,70 @@ static int fused_prepare(lbm_ctx* c) {
         const double eff = (double)wgs / (double)((wgs + ncu - 1) / ncu * ncu) * zc / (zc + 2.0);
         if (eff > best_eff + 1e-9) { best_eff = eff; best_nbz = nbz; }
     }
-    if (c->f2_zsplit > 0 && c->f2_zsplit <= 256) {
+    if (c->f2_zsplit > 0) {
         const int zc = (nz + c->f2_zsplit - 1) / c->f2_zsplit;
         if (zc <= max_chunk) best_nbz = (nz + zc - 1) / zc;
     }
     if (best_nbz == 0) return LBM_OK;
     fg.zchunk = (nz + best_nbz - 1) / best_nbz;
-    fg.nbz = (nz + fg.zchunk - 1) / fg.zchunk;
+    fg.nbz = best_nbz;
 
-    // tile flags -> host
-    const long long ntiles = (long long)g.D * g.H * g.Wt;
-    std::vector<unsigned char> fl((size_t)ntiles);
-    HIPCHK(c, hipMemcpyAsync(fl.data(), c->flags, (size_t)ntiles, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    auto tile = [&](int xs, int y, int z) -> size_t { return ((size_t)z * g.H + y) * g.Wt + xs; };   // z = zl - 1
-
-    // block eligibility: every tile the block's first step touches (one more tile in x, one row in y, one
-    // layer in z on every side) is an interior tile (flag 0)
-    const size_t nblocks = (size_t)fg.nbx * fg.nby * fg.nbz;
-    std::vector<unsigned char> elig(nblocks, 0), covered((size_t)ntiles, 0);
+    // Blocks: for every tile column (x tile, y tile) the maximal runs of layers in which every tile the first
+    // step touches -- one more tile in x and one more row in y on every side -- is an interior tile (flag 0).
+    // A run of clean layers [a, b] carries second steps for the layers a+1 .. b-1; runs are cut into pieces of
+    // at most zchunk layers, and pieces too short to pay for their two lead-in layers are left to the rim.
+    constexpr int MIN_LAYERS = 6;
+    struct Block { unsigned bx, by, zs, len; };
+    std::vector<std::vector<Block>> per_row((size_t)fg.nby);
+    std::vector<unsigned char> covered((size_t)ntiles, 0);
     long long fused_cells = 0;
-#pragma omp parallel for collapse(2) schedule(dynamic, 8) reduction(+ : fused_cells)
-    for (int bz = 0; bz < fg.nbz; bz++)
-        for (int by = 0; by < fg.nby; by++) {
-            const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
-            const int zs = fg.zl_first + bz * fg.zchunk, ze = std::min(zs + fg.zchunk, fg.zl_end);
-            for (int bx = 0; bx < fg.nbx; bx++) {
-                bool ok = true;
-                for (int z = zs - 2; z <= ze - 1 && ok; z++)
-                    for (int y = y0 - 1; y <= y0 + tyn && ok; y++)
-                        for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
-                            if (fl[tile(xs, y, z)] != 0) { ok = false; break; }
-                if (!ok) continue;
-                elig[((size_t)bz * fg.nby + by) * fg.nbx + bx] = 1;
-                for (int z = zs - 1; z <= ze - 2; z++)
-                    for (int y = y0; y < y0 + tyn; y++) covered[tile(bx, y, z)] = 1;
-                fused_cells += (long long)std::min(64, g.W - bx * 64) * tyn * (ze - zs);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : fused_cells)
+    for (int by = 0; by < fg.nby; by++) {
+        const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
+        for (int bx = 0; bx < fg.nbx; bx++) {
+            auto clean = [&](int z) {
+                for (int y = y0 - 1; y <= y0 + tyn; y++)
+                    for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
+                        if (fl[tile(xs, y, z)] != 0) return false;
+                return true;
+            };
+            int z = 0;
+            while (z < g.D) {
+                if (!clean(z)) { z++; continue; }
+                int a = z;
+                while (z < g.D && clean(z)) z++;
+                const int b = z - 1;                                 // clean layers [a, b] (0-based z)
+                const int len = b - a - 1;                           // second-step layers a+1 .. b-1
+                if (len < MIN_LAYERS) continue;
+                const int pieces = (len + fg.zchunk - 1) / fg.zchunk;
+                const int per = (len + pieces - 1) / pieces;
+                for (int s0 = 0; s0 < len; s0 += per) {
+                    const int n = std::min(per, len - s0);
+                    const int zs = a + 1 + s0 + 1;                   // local layer index (ghost offset): z + 1
+                    per_row[(size_t)by].push_back({(unsigned)bx, (unsigned)by, (unsigned)zs, (unsigned)n});
+                    for (int zz = zs - 1; zz < zs - 1 + n; zz++)
+                        for (int y = y0; y < y0 + tyn; y++) covered[tile(bx, y, zz)] = 1;
+                    fused_cells += (long long)std::min(64, g.W - bx * 64) * tyn * n;
+                }
             }
         }
+    }
     if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
-    std::vector<unsigned> blocks;
-    for (size_t b = 0; b < nblocks; b++)
-        if (elig[b]) {
-            const unsigned bx = (unsigned)(b % fg.nbx), by = (unsigned)((b / fg.nbx) % fg.nby), bz = (unsigned)(b / ((size_t)fg.nbx * fg.nby));
-            blocks.push_back(bx | (by << 12) | (bz << 24));
-        }
+    // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
+    // (and the contiguous ranges the XCDs take, k_fused2.h) are neighbours in space; long blocks first within
+    // a range so that the short ones fill the tail
+    std::vector<Block> all;
+    for (auto& v : per_row) all.insert(all.end(), v.begin(), v.end());
+    std::stable_sort(all.begin(), all.end(), [&](const Block& p, const Block& q) {
+        const unsigned cp = (p.zs - 1) / (unsigned)fg.zchunk, cq = (q.zs - 1) / (unsigned)fg.zchunk;
+        if (cp != cq) return cp < cq;
+        if (p.by != q.by) return p.by < q.by;
+        return p.bx < q.bx;
+    });
+    std::vector<unsigned long long> blocks;
+    blocks.reserve(all.size());
+    for (const Block& k : all)
+        blocks.push_back((unsigned long long)k.bx | ((unsigned long long)k.by << 12) | ((unsigned long long)k.zs << 24) | ((unsigned long long)k.len << 44));
     fg.nblocks = (int)blocks.size();
 
     // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
@@ -610,7 +650,7 @@ static int fused_prepare(lbm_ctx* c) {
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream, c->f[c->cur], c->ft, c->mask, c->g);
         HIPCHK(c, hipGetLastError());
     }
-    int rc = fused_upload(c, (void**)&c->f2_blocks, &c->f2_blocks_cap, blocks.data(), blocks.size() * sizeof(unsigned));
+    int rc = fused_upload(c, (void**)&c->f2_blocks, &c->f2_blocks_cap, blocks.data(), blocks.size() * sizeof(unsigned long long));
     for (int i = 0; i < 2 && !rc; i++) {
         rc = fused_upload(c, (void**)&c->rim_list[i], &c->rim_cap[i], list[i].data(), list[i].size() * sizeof(unsigned long long));
         c->rim_n[i] = list[i].size();
@@ -839,7 +879,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     // alternating z direction = +2.5 % over plain loads / nt stores.  LBM_TUNE overrides for A/B runs.
     // In place (AA) the write-through stores lose: partial-line neighbour writes no longer combine
     // in L2 (4.24 vs 5.39 TB/s), so AA keeps nt loads + nt stores + alternating z direction.
-    // Row-interleaved A/B (tools/tune_bench.py, 256^3): nt loads + nt stores 6.08 TB/s, with sc1 stores
+    // Row-interleaved A/B (tools/probes/tune_bench.py, 256^3): nt loads + nt stores 6.08 TB/s, with sc1 stores
     // 5.5, with alternating z 6.03 -> plain nt/nt is the default there.
     c->tune = o.scheme == LBM_SCHEME_AA ? 5 : (layout == LBM_LAYOUT_ROWS ? 1 : 7);
     if (const char* t = getenv("LBM_TUNE")) c->tune = atoi(t);
@@ -847,7 +887,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     {   // Workgroups go to the 8 XCDs round-robin in launch order.  When the workgroups per row divide 8
         // (W <= 2048 in powers of two) that hands every XCD a fixed x segment, which runs well; otherwise
         // (e.g. W = 1504: 6 per row) the assignment wanders, and giving each XCD whole rows is 2 % faster
-        // for the pull kernel (5.77 -> 5.92 TB/s at 1504x1536; AA loses 1 %, tools/xcd_rows_probe.py).
+        // for the pull kernel (5.77 -> 5.92 TB/s at 1504x1536; AA loses 1 %, tools/probes/xcd_rows_probe.py).
         const int segsx = 1 << c->segsx_log2, gx = (g.Wt + segsx - 1) / segsx;
         c->xcd_rows = o.scheme != LBM_SCHEME_AA && 8 % gx != 0;
     }

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 def run(W, H, D, preset, scheme, steps=100, warm=20, label=""):
     s = lbm.Solver(W, H, D, preset=preset, scheme=scheme)

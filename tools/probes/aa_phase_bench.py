@@ -1,6 +1,6 @@
 """Even vs odd AA step time (ad-hoc probe)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 dims = tuple(int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 256, 256)
 for preset in (1, 0):

@@ -1,7 +1,7 @@
 """A/B step time against layers per launch on ONE solver instance (the allocation, whose physical
 placement moves the step time by +-3 %, stays the same).  usage: ab_chunk_probe.py W H D preset chunks [ab|aa]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4])
 preset = int(sys.argv[4])

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cfd_amd import lbm
 for dims in ((1024, 64, 64), (1024, 512, 16), (1024, 16, 512), (512, 512, 512), (1024, 512, 512), (1024, 512, 128), (1024, 256, 256)):

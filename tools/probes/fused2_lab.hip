@@ -1,5 +1,5 @@
 // fused2_lab.hip -- tuning lab for the two-steps-per-pass kernel (round 2).  NOT product: interior cells of
-// a fixed 256^3 row-interleaved lattice only, like tools/fused2_proto.hip; it exists to pick the shape of
+// a fixed 256^3 row-interleaved lattice only, like tools/probes/fused2_proto.hip; it exists to pick the shape of
 // cfd_amd/csrc/k_fused2.h by measurement.  One templated kernel covers the variants:
 //   TY     rows per tile (TY + 2 row waves + 1 halo-column wave per workgroup)
 //   STAGE  0: the 19 loads of a layer are issued when they are needed (no prefetch)
@@ -14,7 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "../cfd_amd/csrc/d3q19.h"
+#include "../../cfd_amd/csrc/d3q19.h"
 using namespace d3q19;
 
 constexpr int W = 256, H = 256, D = 256;

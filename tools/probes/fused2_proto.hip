@@ -19,7 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "../cfd_amd/csrc/d3q19.h"
+#include "../../cfd_amd/csrc/d3q19.h"
 using namespace d3q19;
 
 constexpr int W = 256, H = 256, D = 256;

@@ -1,7 +1,7 @@
 """Cost of the boundary (general) path: the same domain with every tile forced onto it, and the share
 of tiles that take it in the car configuration (ad-hoc probe)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cfd_amd import lbm
 car = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "car_like.obj")

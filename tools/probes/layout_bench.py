@@ -1,6 +1,6 @@
 """Step time of both layouts / both schemes at 256^3 (ad-hoc probe; LBM_LAYOUT / LBM_TUNE from env)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 
 def run(W, H, D, preset, scheme, layout, steps=100, warm=20):

@@ -1,6 +1,6 @@
 """Does a domain that fits the 256 MiB Infinity Cache step faster?  (ad-hoc probe)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 
 def run(W, H, D, preset, scheme=0, steps=200, warm=20):

@@ -5,7 +5,7 @@
 //        bit2: two rows per wave (38 loads in flight)   bit3: sc1 stores instead of nt
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../cfd_amd/csrc/d3q19.h"
+#include "../../cfd_amd/csrc/d3q19.h"
 using namespace d3q19;
 constexpr int W = 256, H = 256, D = 256, DP = D + 2;
 

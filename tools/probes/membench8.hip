@@ -2,7 +2,7 @@
 // against plain misaligned loads (row-interleaved layout, real collision).  See membench7.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../cfd_amd/csrc/d3q19.h"
+#include "../../cfd_amd/csrc/d3q19.h"
 using namespace d3q19;
 constexpr int W = 256, H = 256, D = 256, HP = H + 2, DP = D + 2;
 

@@ -2,7 +2,7 @@
 two allocations against one allocation with a chosen distance between the buffers (ad-hoc probe).
 usage: placement_probe.py W H D preset"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4])
 preset = int(sys.argv[4])

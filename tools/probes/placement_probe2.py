@@ -1,7 +1,7 @@
 """Is the bimodal step time a property of the solver instance (its allocation) or of the moment?
 Three live instances timed in turn, several rounds (ad-hoc probe).  usage: placement_probe2.py W H D preset"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4])
 preset = int(sys.argv[4])

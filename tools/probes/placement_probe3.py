@@ -1,7 +1,7 @@
 """256^3 cavity, A/B: two allocations against both buffers in one allocation (LBM_AB_SINGLE), fresh
 solvers in alternation (ad-hoc probe)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 256, 256)
 preset = int(sys.argv[4]) if len(sys.argv) > 4 else 1

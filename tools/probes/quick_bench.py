@@ -1,6 +1,6 @@
 """Ad-hoc timing probe used while tuning (not the driver's bench.py)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 
 def run(W, H, D, preset, steps=100, warm=20, skew=-1, label=""):

@@ -2,7 +2,7 @@
 itself through torch.distributed/nccl.  Checks bit-identity against the undecomposed solver and
 reports host+device time per step of the overlapped schedule."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import torch.distributed as dist

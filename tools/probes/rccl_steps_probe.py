@@ -1,6 +1,6 @@
 """Host enqueue vs total time of the RCCL slab step as the step count grows (one rank, ring to itself)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
 from cfd_amd import lbm, slab

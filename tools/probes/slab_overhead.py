@@ -2,7 +2,7 @@
 run on ONE GPU one after the other (device copies as transport): time per step of the whole domain against
 the undecomposed run.  (ad-hoc probe; the real exchange runs over RCCL between GPUs)"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cfd_amd import lbm, slab
 W, H, Dg = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (1024, 512, 512)

@@ -2,7 +2,7 @@
 sweeps apart (ad-hoc probe).  chunk 0 = A/B in one launch, chunk < 0 = A/B in launches of -chunk layers.
 usage: slide_bench.py W H D preset chunk[,chunk..] [row_pad[,row_pad..] [skew_bytes[,..]]]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4])
 preset = int(sys.argv[4])

@@ -1,7 +1,7 @@
 """Whole rows of workgroups per XCD (ZORDER_XCD, k_step.h) against the plain launch order, on ONE
 solver instance.  usage: xcd_rows_probe.py W H D preset chunk [ab|aa]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cfd_amd import lbm
 W, H, D = (int(a) for a in sys.argv[1:4])
 preset = int(sys.argv[4])
