@@ -148,7 +148,7 @@ LBM_HD void collide_cell(const float* f, const Moments& m, float omega_shear, fl
 
     out[0] = w0r * (1.0f - c15) + c0 * d000;
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LBM_NO_PACKED_PAIRS)
     // Directions k and inv(k) run through the same five operations on (+a, -a): written on two-float vectors
     // so that they issue as packed instructions (v_pk_add_f32 / v_pk_mul_f32, two results per issue slot).
     // Each component is the same IEEE operation sequence as the scalar form below: 1 + a, + b, - c15, * w rho,

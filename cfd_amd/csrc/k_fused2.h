@@ -165,10 +165,14 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         const unsigned total = gridDim.x, launch = blockIdx.x;
         const unsigned xcd = launch & 7u, nth = launch >> 3, q = total >> 3, r = total & 7u;
         const unsigned long long e = blocks[F2_XCD_REMAP ? xcd * q + min(xcd, r) + nth : launch];
-        bx = (int)(e & 0xfffu);
-        by = (int)((e >> 12) & 0xfffu);
-        zs = (int)((e >> 24) & 0xfffffu);
-        ze = zs + (int)(e >> 44);
+        // the entry is the same for the whole workgroup: keep what is derived from it in scalar registers
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+        bx = (int)(lo & 0xfffu);
+        by = (int)((lo >> 12) & 0xfffu);
+        zs = (int)((lo >> 24) | ((hi & 0xfffu) << 8));
+        // (the host never lets a block run past zl_end; written as a min() the compiler cannot derive a minimum trip
+        // count of the layer loop from the entry's layout, which made it peel the loop and spill 18 registers)
+        ze = min(zs + (int)(hi >> 12), fg.zl_end);
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int role = f2_role<TY>(wave);

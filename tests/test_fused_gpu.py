@@ -96,7 +96,7 @@ def test_fused_mask_params_reset(oracle, lbm):
         s.set_params(inlet_velocity=0.05, omega_shear=1.7, omega_bulk=1.6)
     o.step(7); g.step(7)
     same(o, g, "after add_solid + set_params")
-    if fused_in_use(lbm, g):
+    if fused_in_use(lbm, g, may_decline=True):          # the box leaves little of this small domain to 12-row tiles
         assert g.stats()["fused_cells"] < c0
     m = o.solid_mask().reshape(D, H, W).copy()
     m[:, 8:17, 40:70] = 0                               # the box turns fluid again (frozen populations thaw)
