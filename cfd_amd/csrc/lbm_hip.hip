@@ -128,6 +128,11 @@ struct lbm_ctx {
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
     bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
     bool f2_rim_pending = false;   // the side stream holds rim launches the context's stream has not waited for yet
+    // a PAIR of steps on a z-slab (lbm_pair_*): 0 idle, 1 boundary layers of the first step issued, 2 interior issued,
+    // 3 boundary layers of the second step issued
+    int pair_phase = 0;
+    hipEvent_t ev_pair_b1 = nullptr, ev_pair_r1 = nullptr;
+    bool pair_last = false;        // the last update was a pair: the previous buffer is TWO steps old (no rho/u on demand)
     std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
     size_t f2_ev_used = 0;
     bool timing = false;
@@ -438,8 +443,11 @@ static inline float* halo_lattice(lbm_ctx* c) {
 //     k_stream_collide<4> ft     -> f[1-cur]   (t+1 -> t+2 on the rim)
 // The three launches write disjoint cells; the second pair is ordered by the stream.  fused_prepare() derives
 // block eligibility and the two tile lists from the tile flags (on the host: it runs once per mask change).
-static bool fused_applies(const lbm_ctx* c) {
+static bool fused_applies(const lbm_ctx* c) {   // lbm_step() on an undecomposed context
     return c->fused_on && c->scheme == LBM_SCHEME_AB && !c->g.slab && c->layout == LBM_LAYOUT_ROWS;
+}
+static bool fused_applies_slab(const lbm_ctx* c) {   // lbm_pair_*() on a z-slab
+    return c->fused_on && c->scheme == LBM_SCHEME_AB && c->g.slab && c->layout == LBM_LAYOUT_ROWS && c->g.D >= 6;
 }
 
 struct F2Variant { int ty, stage, nbuf; };
@@ -530,38 +538,16 @@ static int fused_prepare(lbm_ctx* c) {
     if (fg.y_end - fg.y_first < 1) return LBM_OK;
     fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
     if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 bits for the y tile
-    fg.zl_first = 3; fg.zl_end = g.D - 1;                           // widest possible range of second-step layers
-    const int nz = fg.zl_end - fg.zl_first;
-    // Layers per block for an unobstructed tile column: whole rounds of one workgroup per CU, against the two
-    // redundant first-step layers every block starts with.
-    int best_nbz = 0;
-    double best_eff = -1.0;
-    for (int nbz = 1; nbz <= std::min(nz, 256); nbz++) {
-        const int zc = (nz + nbz - 1) / nbz;
-        if (zc > max_chunk) continue;
-        if ((nz + zc - 1) / zc != nbz) continue;                     // the same chunk length as a smaller count
-        const long long wgs = (long long)fg.nbx * fg.nby * nbz;
-        const double eff = (double)wgs / (double)((wgs + ncu - 1) / ncu * ncu) * zc / (zc + 2.0);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best_nbz = nbz; }
-    }
-    if (c->f2_zsplit > 0) {
-        const int zc = (nz + c->f2_zsplit - 1) / c->f2_zsplit;
-        if (zc <= max_chunk) best_nbz = (nz + zc - 1) / zc;
-    }
-    if (best_nbz == 0) return LBM_OK;
-    fg.zchunk = (nz + best_nbz - 1) / best_nbz;
-    fg.nbz = best_nbz;
+    fg.zl_first = g.slab ? 2 : 3;                                   // widest possible range of second-step layers:
+    fg.zl_end = g.slab ? g.D : g.D - 1;                             // a slab's outer layers are its boundary layers, a domain's its walls
 
-    // Blocks: for every tile column (x tile, y tile) the maximal runs of layers in which every tile the first
-    // step touches -- one more tile in x and one more row in y on every side -- is an interior tile (flag 0).
-    // A run of clean layers [a, b] carries second steps for the layers a+1 .. b-1; runs are cut into pieces of
-    // at most zchunk layers, and pieces too short to pay for their two lead-in layers are left to the rim.
-    constexpr int MIN_LAYERS = 6;
-    struct Block { unsigned bx, by, zs, len; };
-    std::vector<std::vector<Block>> per_row((size_t)fg.nby);
-    std::vector<unsigned char> covered((size_t)ntiles, 0);
-    long long fused_cells = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : fused_cells)
+    // Runs: for every tile column (x tile, y tile) the maximal runs of layers in which every tile the first step
+    // touches -- one more tile in x and one more row in y on every side -- is an interior tile (flag 0).  A run of
+    // clean layers [a, b] carries second steps for the layers a+1 .. b-1.
+    constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
+    struct Run { int bx, by, a, len; };
+    std::vector<std::vector<Run>> runs_of((size_t)fg.nby);
+#pragma omp parallel for schedule(dynamic, 1)
     for (int by = 0; by < fg.nby; by++) {
         const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
         for (int bx = 0; bx < fg.nbx; bx++) {
@@ -574,30 +560,63 @@ static int fused_prepare(lbm_ctx* c) {
             int z = 0;
             while (z < g.D) {
                 if (!clean(z)) { z++; continue; }
-                int a = z;
+                const int a = z;
                 while (z < g.D && clean(z)) z++;
-                const int b = z - 1;                                 // clean layers [a, b] (0-based z)
-                const int len = b - a - 1;                           // second-step layers a+1 .. b-1
-                if (len < MIN_LAYERS) continue;
-                const int pieces = (len + fg.zchunk - 1) / fg.zchunk;
-                const int per = (len + pieces - 1) / pieces;
-                for (int s0 = 0; s0 < len; s0 += per) {
-                    const int n = std::min(per, len - s0);
-                    const int zs = a + 1 + s0 + 1;                   // local layer index (ghost offset): z + 1
-                    per_row[(size_t)by].push_back({(unsigned)bx, (unsigned)by, (unsigned)zs, (unsigned)n});
-                    for (int zz = zs - 1; zz < zs - 1 + n; zz++)
-                        for (int y = y0; y < y0 + tyn; y++) covered[tile(bx, y, zz)] = 1;
-                    fused_cells += (long long)std::min(64, g.W - bx * 64) * tyn * n;
-                }
+                const int len = (z - 1) - a - 1;                     // clean layers [a, z-1] (0-based): second steps a+1 .. z-2
+                if (len >= MIN_LAYERS) runs_of[(size_t)by].push_back({bx, by, a, len});
             }
+        }
+    }
+    std::vector<Run> runs;
+    for (auto& v : runs_of) runs.insert(runs.end(), v.begin(), v.end());
+    if (runs.empty()) return LBM_OK;
+
+    // Layers per block.  A block costs its layers + two lead-in layers of first steps; the launch takes as many
+    // rounds as its blocks need at one workgroup per CU.  Pick the piece length with the least rounds x (layers + 2).
+    int zchunk = 0;
+    if (c->f2_zsplit > 0) {
+        zchunk = std::min(max_chunk, std::max(MIN_LAYERS, (fg.zl_end - fg.zl_first + c->f2_zsplit - 1) / c->f2_zsplit));
+    } else {
+        double best = 1e300;
+        int longest = 0;
+        for (const Run& r : runs) longest = std::max(longest, r.len);
+        for (int zc = std::min(longest, max_chunk); zc >= MIN_LAYERS; zc--) {
+            long long blocks = 0;
+            int piece_max = 0;
+            for (const Run& r : runs) {
+                const int pieces = (r.len + zc - 1) / zc;
+                blocks += pieces;
+                piece_max = std::max(piece_max, (r.len + pieces - 1) / pieces);
+            }
+            const double cost = (double)((blocks + ncu - 1) / ncu) * (piece_max + 2);
+            if (cost < best - 1e-9) { best = cost; zchunk = zc; }
+        }
+    }
+    if (zchunk < 1) return LBM_OK;
+    fg.zchunk = zchunk;
+    fg.nbz = (fg.zl_end - fg.zl_first + zchunk - 1) / zchunk;
+
+    struct Block { unsigned bx, by, zs, len; };
+    std::vector<Block> all;
+    std::vector<unsigned char> covered((size_t)ntiles, 0);
+    long long fused_cells = 0;
+    for (const Run& r : runs) {
+        const int y0 = fg.y_first + r.by * TY, tyn = std::min(TY, fg.y_end - y0);
+        const int pieces = (r.len + zchunk - 1) / zchunk;
+        const int per = (r.len + pieces - 1) / pieces;
+        for (int s0 = 0; s0 < r.len; s0 += per) {
+            const int n = std::min(per, r.len - s0);
+            const int zs = r.a + 1 + s0 + 1;                         // local layer index (ghost offset): z + 1
+            all.push_back({(unsigned)r.bx, (unsigned)r.by, (unsigned)zs, (unsigned)n});
+            for (int zz = zs - 1; zz < zs - 1 + n; zz++)
+                for (int y = y0; y < y0 + tyn; y++) covered[tile(r.bx, y, zz)] = 1;
+            fused_cells += (long long)std::min(64, g.W - r.bx * 64) * tyn * n;
         }
     }
     if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
     // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
     // (and the contiguous ranges the XCDs take, k_fused2.h) are neighbours in space; long blocks first within
     // a range so that the short ones fill the tail
-    std::vector<Block> all;
-    for (auto& v : per_row) all.insert(all.end(), v.begin(), v.end());
     std::stable_sort(all.begin(), all.end(), [&](const Block& p, const Block& q) {
         const unsigned cp = (p.zs - 1) / (unsigned)fg.zchunk, cq = (q.zs - 1) / (unsigned)fg.zchunk;
         if (cp != cq) return cp < cq;
@@ -638,6 +657,7 @@ static int fused_prepare(lbm_ctx* c) {
             for (int xs = 0; xs < g.Wt; xs++) {
                 const size_t t = tile(xs, y, z);
                 if (fl[t] == 2) continue;
+                if (g.slab && (z == 0 || z == g.D - 1)) continue;   // a slab's boundary layers: lbm_pair_boundary_*()
                 const unsigned long long e = (unsigned long long)xs | ((unsigned long long)y << 16) | ((unsigned long long)(z + 1) << 40);
                 if (a[t]) list[0].push_back(e);
                 if (rim[t]) { list[1].push_back(e); rim_cells += std::min(64, g.W - xs * 64); }
@@ -724,6 +744,8 @@ static int materialise_fields(lbm_ctx* c) {
         HIPCHK(c, hipGetLastError());
     } else if (c->scheme != LBM_SCHEME_AB) {
         return fail(c, LBM_ERR_STATE, "in-place schemes: rho/u of a new field window exist after the next lbm_step()");
+    } else if (c->pair_last) {
+        return fail(c, LBM_ERR_STATE, "the last update was a pair of steps (lbm_pair_*): rho/u exist again after the next single step");
     } else if (c->prev_touched) {
         // the fields of the last step were settled with the old mask and then dropped by a window change;
         // the buffer they came from has been re-frozen with the new mask since
@@ -987,6 +1009,8 @@ int lbm_destroy(lbm_ctx* c) {
     if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
     if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);
     if (c->ev_f2_rim) hipEventDestroy(c->ev_f2_rim);
+    if (c->ev_pair_b1) hipEventDestroy(c->ev_pair_b1);
+    if (c->ev_pair_r1) hipEventDestroy(c->ev_pair_r1);
     hipFree(c->rho); hipFree(c->u); hipFree(c->curl); hipFree(c->solid_dense);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -1018,6 +1042,7 @@ int lbm_init(lbm_ctx* c) {
     if (c->ft) c->mask_dirty = true;  // the third buffer's frozen solid cells must follow (k_sync_solid)
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
     c->prev_touched = false;
+    c->pair_last = false;
     c->curl_valid = false;
     return LBM_OK;
 }
@@ -1172,7 +1197,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     NEED(c);
     if (nsteps < 0) return fail(c, LBM_ERR_INVALID, "lbm_step: nsteps %d", nsteps);
     if (nsteps == 0) return LBM_OK;
-    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step: a split step is in flight (lbm_step_finish missing)");
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step: a split step is in flight (lbm_step_finish / lbm_pair_finish missing)");
     int rc = refresh_mask_state(c);
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_AA) {
@@ -1230,6 +1255,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     c->steps += (uint64_t)nsteps;
     c->fields = fuse ? FIELDS_VALID : FIELDS_STALE;
     c->prev_touched = false;
+    c->pair_last = false;
     c->fields_wanted = false;
     c->curl_valid = false;
     return LBM_OK;
@@ -1700,7 +1726,7 @@ int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n
 
 int lbm_step_boundary_layers(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
     NEED(c);
-    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: previous split step not finished");
     if ((d_msg_bottom || d_msg_top) && !c->g.slab)
         return fail(c, LBM_ERR_STATE, "lbm_step_boundary_layers: messages need a slab context");
     const bool was_dirty = c->mask_dirty;
@@ -1763,8 +1789,104 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
         return fail(c, LBM_ERR_STATE, "lbm_halo_unpack_both: sliding scheme: the ghost layers of the new lattice position are free only after lbm_step_interior_layers");
     const long long per = c->g.mlayer > c->g.H + 2 ? c->g.mlayer : c->g.H + 2;
     float* dst = halo_lattice(c);
-    hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, c->stream, dst, d_from_below, d_from_above, c->g);
+    hipStream_t stream = c->stream;
+    if (c->pair_phase) {
+        // a pair of steps in flight (lbm_pair_*): the messages of its first step go into the ghost layers of the
+        // intermediate buffer, those of its second step into the new state's; on the boundary stream, so that they
+        // do not queue behind the fused kernel
+        if (c->pair_phase == 1) return fail(c, LBM_ERR_STATE, "lbm_halo_unpack_both: call lbm_pair_interior first");
+        dst = c->pair_phase == 2 ? c->ft : c->f[1 - c->cur];
+        if (c->stream_b) stream = c->stream_b;
+    }
+    hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, stream, dst, d_from_below, d_from_above, c->g);
     HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
+// ---- a PAIR of steps on a z-slab: the fused kernel for the interior, the boundary layers and the rim stepped twice
+int lbm_pair_available(lbm_ctx* c, int* available) {
+    NEED(c);
+    if (!available) return fail(c, LBM_ERR_INVALID, "lbm_pair_available: null argument");
+    *available = 0;
+    if (!fused_applies_slab(c) || c->split_phase != 0 || c->pair_phase != 0) return LBM_OK;
+    const bool was_dirty = c->mask_dirty;
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = fused_prepare(c);
+    if (rc) return rc;
+    if (was_dirty && c->stream_b) {  // set-up kernels ran on the main stream: order the boundary stream behind them
+        HIPCHK(c, hipEventRecord(c->ev_order, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_b, c->ev_order, 0));
+    }
+    *available = c->fused_usable ? 1 : 0;
+    return LBM_OK;
+}
+
+int lbm_pair_boundary_first(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
+    NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_pair_boundary_first: a split step or a pair is in flight");
+    if (!fused_applies_slab(c)) return fail(c, LBM_ERR_STATE, "lbm_pair_boundary_first: pairs need an A/B slab context with lbm_opts.two_step on");
+    int avail = 0;
+    int rc = lbm_pair_available(c, &avail);
+    if (rc) return rc;
+    if (!avail) return fail(c, LBM_ERR_STATE, "lbm_pair_boundary_first: the fused path does not apply to this slab (ask lbm_pair_available)");
+    if (!c->ev_pair_b1) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pair_b1, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pair_r1, hipEventDisableTiming));
+    }
+    hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
+    // first step of the two boundary layers: t -> t+1 into the intermediate buffer, messages written as it goes
+    rc = launch_stream_collide<2>(c, c->f[c->cur], c->ft, c->p, 1, 2, c->g.D, d_msg_bottom, d_msg_top, 0, bs);
+    if (rc) return rc;
+    if (bs != c->stream) HIPCHK(c, hipEventRecord(c->ev_pair_b1, bs));
+    c->pair_phase = 1;
+    return LBM_OK;
+}
+
+int lbm_pair_interior(lbm_ctx* c) {
+    NEED(c);
+    if (c->pair_phase != 1) return fail(c, LBM_ERR_STATE, "lbm_pair_interior: call lbm_pair_boundary_first first");
+    hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
+    const float* in = c->f[c->cur];
+    float* out = c->f[1 - c->cur];
+    // the rim's first step before the fused kernel: the boundary stream waits for it alone (the second step of the
+    // boundary layers pulls from the layers next to them)
+    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[0], c->rim_n[0]);
+    if (rc) return rc;
+    if (bs != c->stream) HIPCHK(c, hipEventRecord(c->ev_pair_r1, c->stream));
+    hipError_t e = launch_fused(c, in, out);
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "k_fused2 launch failed: %s", hipGetErrorString(e));
+    c->fused_launches++;
+    // the rim's second step pulls from the boundary layers' first step
+    if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pair_b1, 0));
+    rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[1], c->rim_n[1]);
+    if (rc) return rc;
+    c->pair_phase = 2;
+    return LBM_OK;
+}
+
+int lbm_pair_boundary_second(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) {
+    NEED(c);
+    if (c->pair_phase != 2) return fail(c, LBM_ERR_STATE, "lbm_pair_boundary_second: call lbm_pair_interior (and unpack the first step's messages) first");
+    hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
+    if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(bs, c->ev_pair_r1, 0));
+    // second step of the two boundary layers: t+1 -> t+2, from the intermediate buffer (ghost layers just unpacked)
+    int rc = launch_stream_collide<2>(c, c->ft, c->f[1 - c->cur], c->p, 1, 2, c->g.D, d_msg_bottom, d_msg_top, 0, bs);
+    if (rc) return rc;
+    c->pair_phase = 3;
+    return LBM_OK;
+}
+
+int lbm_pair_finish(lbm_ctx* c) {
+    NEED(c);
+    if (c->pair_phase != 3) return fail(c, LBM_ERR_STATE, "lbm_pair_finish: call lbm_pair_boundary_second first");
+    c->cur = 1 - c->cur;
+    c->p_last = c->p;
+    c->steps += 2;
+    c->fields = FIELDS_STALE;
+    c->pair_last = true;   // the previous buffer is two steps old: no rho/u on demand until a single step has run
+    c->prev_touched = false;
+    c->curl_valid = false;
+    c->pair_phase = 0;
     return LBM_OK;
 }
 
@@ -1802,6 +1924,7 @@ int lbm_step_finish(lbm_ctx* c) {
     c->steps += 1;
     c->fields = c->scheme == LBM_SCHEME_AB ? FIELDS_STALE : FIELDS_VALID;
     c->prev_touched = false;
+    c->pair_last = false;
     c->curl_valid = false;
     c->split_phase = 0;
     return LBM_OK;

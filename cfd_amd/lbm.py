@@ -98,6 +98,11 @@ SIGNATURES = {
     "lbm_step_boundary_layers": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_step_interior_layers": ([_ctx], C.c_int),
     "lbm_step_finish": ([_ctx], C.c_int),
+    "lbm_pair_available": ([_ctx, C.POINTER(C.c_int)], C.c_int),
+    "lbm_pair_boundary_first": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
+    "lbm_pair_interior": ([_ctx], C.c_int),
+    "lbm_pair_boundary_second": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
+    "lbm_pair_finish": ([_ctx], C.c_int),
 }
 
 _lib = None

@@ -138,6 +138,33 @@ class HipSlabEngine:
     def step_interior(self):
         self.solver._chk(self._lib.lbm_step_interior_layers(self._ctx))
 
+    # a PAIR of steps (include/lbm_abi.h lbm_pair_*): fused interior, boundary layers and rim stepped twice
+    def pair_available(self):
+        import ctypes as C
+        a = C.c_int(0)
+        self.solver._chk(self._lib.lbm_pair_available(self._ctx, C.byref(a)))
+        return bool(a.value)
+
+    def pair_boundary_first(self, msg_bottom=None, msg_top=None):
+        self._check_message(msg_bottom)
+        self._check_message(msg_top)
+        self.solver._chk(self._lib.lbm_pair_boundary_first(
+            self._ctx, None if msg_bottom is None else msg_bottom.data_ptr(),
+            None if msg_top is None else msg_top.data_ptr()))
+
+    def pair_interior(self):
+        self.solver._chk(self._lib.lbm_pair_interior(self._ctx))
+
+    def pair_boundary_second(self, msg_bottom=None, msg_top=None):
+        self._check_message(msg_bottom)
+        self._check_message(msg_top)
+        self.solver._chk(self._lib.lbm_pair_boundary_second(
+            self._ctx, None if msg_bottom is None else msg_bottom.data_ptr(),
+            None if msg_top is None else msg_top.data_ptr()))
+
+    def pair_finish(self):
+        self.solver._chk(self._lib.lbm_pair_finish(self._ctx))
+
     step_phase_interior = step_interior
 
     def step_finish(self):
@@ -200,6 +227,7 @@ class SlabSolver:
         self.down, self.up = neighbours(preset, world, rank)
         self.send = [engine.new_message(), engine.new_message()]
         self.recv = [engine.new_message(), engine.new_message()]
+        self.use_pairs = os.environ.get("LBM_SLAB_PAIRS", "1") != "0"
 
     # message leaving through our TOP face goes to `up` and lands on its BOTTOM ghost, and vice versa
     def _items(self, send, recv):
@@ -289,7 +317,26 @@ class SlabSolver:
         msg_t = self.send[SIDE_TOP] if self.up is not None else None
         rcv_b = self.recv[SIDE_BOTTOM] if self.down is not None else None
         rcv_t = self.recv[SIDE_TOP] if self.up is not None else None
-        for _ in range(nsteps):
+        # Two steps per exchange pattern where the engine offers it (HIP A/B slabs on two streams): the fused
+        # kernel advances the interior by two steps while the boundary layers take two ordinary steps, each
+        # followed by its exchange.  The last step of a batch stays a single split step (rho/u on demand).
+        pairs = 0
+        if nsteps >= 3 and side is not None and self.use_pairs and hasattr(e, "pair_available") and e.pair_available():
+            pairs = (nsteps - 1) // 2
+        for _ in range(pairs):
+            side.wait_stream(main)                     # previous step's unpack / swap is done
+            with torch.cuda.stream(side):
+                e.pair_boundary_first(msg_b, msg_t)    # boundary layers t -> t+1 + messages, on the side stream
+            e.pair_interior()                          # rim t -> t+1, fused interior t -> t+2, rim t+1 -> t+2
+            with torch.cuda.stream(side):
+                self.t.wait(self.t.exchange(self._items(self.send, self.recv)))
+                e.halo_unpack_both(rcv_b, rcv_t)       # neighbours' t+1 layers (the library routes them)
+                e.pair_boundary_second(msg_b, msg_t)   # boundary layers t+1 -> t+2 + messages
+                self.t.wait(self.t.exchange(self._items(self.send, self.recv)))
+                e.halo_unpack_both(rcv_b, rcv_t)       # neighbours' t+2 layers into the new state's ghost layers
+            main.wait_stream(side)
+            e.pair_finish()
+        for _ in range(nsteps - 2 * pairs):
             if side is None:
                 # one stream: boundary layers, then the exchange travels while the interior updates
                 e.step_boundary(msg_b, msg_t)
@@ -361,6 +408,41 @@ class LocalSlabCluster:
     def _sync(self):
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+
+    def _exchange_into_ghosts(self):
+        self._sync()
+        self._route()
+        self._sync()
+        for r, e in enumerate(self.engines):
+            down, up = neighbours(self.preset, self.world, r)
+            e.halo_unpack_both(self.recv[r][SIDE_BOTTOM] if down is not None else None,
+                               self.recv[r][SIDE_TOP] if up is not None else None)
+
+    def step_pairs(self, npairs):
+        """npairs x two steps: through the lbm_pair_* calls on the engines that offer them, as two single split
+        steps on the others.  Both send the same two messages per face in the same order (the boundary layers at
+        t+1, then at t+2), so neighbouring slabs may mix the two freely -- as ranks do under SlabSolver."""
+        paired = [hasattr(e, "pair_available") and e.pair_available() for e in self.engines]
+        for _ in range(npairs):
+            for r, e in enumerate(self.engines):
+                msgs = (self.send[r][SIDE_BOTTOM], self.send[r][SIDE_TOP])
+                e.pair_boundary_first(*msgs) if paired[r] else e.step_boundary(*msgs)
+            for r, e in enumerate(self.engines):
+                e.pair_interior() if paired[r] else e.step_interior()
+            self._exchange_into_ghosts()
+            for r, e in enumerate(self.engines):
+                if not paired[r]:
+                    e.step_finish()
+            for r, e in enumerate(self.engines):
+                msgs = (self.send[r][SIDE_BOTTOM], self.send[r][SIDE_TOP])
+                e.pair_boundary_second(*msgs) if paired[r] else e.step_boundary(*msgs)
+            for r, e in enumerate(self.engines):
+                if not paired[r]:
+                    e.step_interior()
+            self._exchange_into_ghosts()
+            for r, e in enumerate(self.engines):
+                e.pair_finish() if paired[r] else e.step_finish()
+        return paired
 
     def step(self, nsteps=1):
         for _ in range(nsteps):

@@ -282,6 +282,28 @@ int lbm_step_boundary_layers(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top
 int lbm_step_interior_layers(lbm_ctx* ctx);
 int lbm_step_finish(lbm_ctx* ctx);
 
+/* TWO steps per exchange pattern on a slab (lbm_opts.two_step, A/B, row-interleaved layout): the interior advances
+ * by two steps in one pass (k_fused2), only the two boundary layers and the rim are stepped twice, and each of
+ * their steps is followed by the usual exchange -- the same messages as two single split steps, with the fused
+ * kernel running beside both exchanges.  One pair =
+ *     lbm_pair_boundary_first(msg_b, msg_t)    boundary layers t -> t+1, writes the outgoing messages   [boundary stream]
+ *     lbm_pair_interior()                      rim t -> t+1, fused interior t -> t+2, rim t+1 -> t+2    [stream]
+ *     <exchange>, lbm_halo_unpack_both(...)    the neighbours' t+1 layers (the library routes them into the
+ *                                              intermediate buffer, on the boundary stream)
+ *     lbm_pair_boundary_second(msg_b, msg_t)   boundary layers t+1 -> t+2, messages                     [boundary stream]
+ *     <exchange>, lbm_halo_unpack_both(...)    the neighbours' t+2 layers into the new state's ghost layers
+ *     lbm_pair_finish()                        after the caller has joined the two streams
+ * The library orders its own launches across the two streams; the CALLER orders the exchange behind the boundary
+ * launches and joins the streams before lbm_pair_finish (cfd_amd/slab.py: SlabSolver._pair).  Results equal two
+ * single steps bit for bit.  After a pair rho/u cannot be recomputed on demand (the previous buffer is two steps
+ * old): finish a batch with a single split step, as lbm_step() does for undecomposed contexts.
+ * lbm_pair_available reports (after bringing the tile lists up to date) whether the fused path applies to this slab. */
+int lbm_pair_available(lbm_ctx* ctx, int* available);
+int lbm_pair_boundary_first(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top);
+int lbm_pair_interior(lbm_ctx* ctx);
+int lbm_pair_boundary_second(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top);
+int lbm_pair_finish(lbm_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif
