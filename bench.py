@@ -201,8 +201,9 @@ def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kern
     if fl and fms > 0:
         # the launch really moves about half of that (one read + one write per TWO updates, plus the tile halo);
         # the counter figure is in profiles/ (rocprofv3 --pmc passes cannot run inside this process)
-        out["note"] = ("two updates per pass: algorithmic bytes are 152 B per cell update as SURVEY.md 8d defines them; "
-                       "HBM traffic per launch is about 0.55-0.6 x that (profiles/r02_*_pmc_traffic.txt)")
+        out["note"] = ("two cell updates per pass: `achieved` prices every update at the 152 algorithmic bytes SURVEY.md 8d "
+                       "defines, so it can exceed the HBM peak; what the launch really moves through HBM is in "
+                       "profiles/r02_*_pmc_traffic.txt (counters cannot be read from inside this process)")
         out["whole_step_frac"] = round(fluid * steps * bytes_per_cell / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["fused_share_of_cells"] = round(stats["fused_cells"] / max(1, stats["cells"]), 4)
         out["fused_share_of_time"] = round(fms / dev_ms, 4)
@@ -346,13 +347,21 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
                "rccl_ranks": world, "slab_layers": D,
                "halo_bytes_per_step_per_gpu": 4 * eng.message_floats() * ((drv.up is not None) + (drv.down is not None)),
                "roofline": roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")}
+        res["two_steps_per_pass"] = res["roofline"]["kernel"] == "k_fused2"
         if want_exposed:
-            # the same slab without any exchange: lbm_step on the slab context (the ghost layers go stale, which
-            # changes no kernel's work); exposed communication = split step with exchange - this
-            fence()
-            solver.timer_begin()
-            solver.step(min(n, 50))
-            ms_plain = solver.timer_end() / min(n, 50)
+            # the same schedule and launches with a transport that moves nothing (the ghost layers go stale, which
+            # changes no kernel's work); exposed communication = step with exchange - step without
+            real, drv.t = drv.t, slab.NoExchange()
+            try:
+                m = max(3, min(n, 51))
+                drv.step(5)
+                fence()
+                t0 = time.perf_counter()
+                drv.step(m)
+                fence()
+                ms_plain = (time.perf_counter() - t0) / m * 1e3
+            finally:
+                drv.t = real
             tp = torch.tensor([ms_plain], dtype=torch.float64, device="cuda")
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
             res["ms_per_step_no_exchange"] = round(float(tp[0]), 5)

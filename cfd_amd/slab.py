@@ -188,6 +188,19 @@ class LoopbackP2P:
         pass
 
 
+class NoExchange:
+    """A transport that moves nothing: the same schedule and launches with stale ghost layers.  For timing what
+    the exchange itself adds to a step (bench.py: exposed communication)."""
+
+    @staticmethod
+    def exchange(items):
+        return []
+
+    @staticmethod
+    def wait(handle):
+        pass
+
+
 class TorchP2P:
     """Halo transport over torch.distributed point-to-point ops (RCCL on GPUs, gloo on CPU)."""
 
