@@ -192,4 +192,127 @@ LBM_HD void collide_cell(const float* f, const Moments& m, float omega_shear, fl
 #undef LBM_PAIR
 }
 
+#if defined(__HIPCC__)
+// moments_of() + collide_cell() in one piece, written on two-float vectors wherever two quantities run through
+// the same operation sequence: (ux, uy), (mxx, myy), (uz, mzz), (mzx, myz), the direction pairs (k, inv k) and
+// the pairs of such pairs that share |c|.  Every component is the same chain of IEEE operations on the same
+// operands in the same order as in the scalar functions above (a - b is a + (-b), 1 - a is 1 + (-a)), so the
+// results are bit-identical; gfx950 issues a two-float operation (v_pk_add_f32 / v_pk_mul_f32) in the slot of
+// one scalar operation, and reads either half of any register pair for either component, so broadcasts and
+// sign flips cost nothing.  Used by k_fused2, which is bound by instruction issue; tests/test_fused_gpu.py
+// compares it with the oracle and with the one-step kernels (which keep the scalar functions).
+typedef float lbm_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void collide_packed(const float* f, float omega_shear, float omega_bulk, float* out) {
+    float rho = f[0];
+    rho += f[1]; rho += f[2]; rho += f[3]; rho += f[4]; rho += f[5]; rho += f[6];
+    rho += f[7]; rho += f[8]; rho += f[9]; rho += f[10]; rho += f[11]; rho += f[12];
+    rho += f[13]; rho += f[14]; rho += f[15]; rho += f[16]; rho += f[17]; rho += f[18];
+    const lbm_v2 p13 = {f[1], f[3]}, p24 = {f[2], f[4]};
+    const lbm_v2 pa = {f[11], f[15]}, pb = {f[12], f[16]}, pc = {f[13], f[17]}, pd = {f[14], f[18]};
+    const lbm_v2 s7 = {f[7], f[7]}, s8 = {f[8], f[8]}, s9 = {f[9], f[9]}, s10 = {f[10], f[10]};
+    lbm_v2 U = p13;                       // (ux, uy): lbm_solver.cu:320-334, k order per component
+    U -= p24; U += s7; U -= s8; U += lbm_v2{f[9], -f[9]}; U += lbm_v2{-f[10], f[10]};
+    U += pa; U -= pb; U += pc; U -= pd;
+    lbm_v2 M = p13;                       // (mxx, myy)
+    M += p24; M += s7; M += s8; M += s9; M += s10; M += pa; M += pb; M += pc; M += pd;
+    lbm_v2 Z = {f[5], f[5]};              // (uz, mzz)
+    Z += lbm_v2{-f[6], f[6]}; Z += lbm_v2{f[11], f[11]}; Z += lbm_v2{-f[12], f[12]};
+    Z += lbm_v2{-f[13], f[13]}; Z += lbm_v2{f[14], f[14]}; Z += lbm_v2{f[15], f[15]};
+    Z += lbm_v2{-f[16], f[16]}; Z += lbm_v2{-f[17], f[17]}; Z += lbm_v2{f[18], f[18]};
+    lbm_v2 D = pa;                        // (mzx, myz)
+    D += pb; D -= pc; D -= pd;
+    float mxy = f[7]; mxy += f[8]; mxy -= f[9]; mxy -= f[10];
+    float uz = Z.x;
+    const float mzz = Z.y;
+    if (rho > 1e-9f) {
+        const float inv_rho = 1.0f / rho;
+        U *= inv_rho; uz *= inv_rho;
+    } else {
+        rho = 1.0f;
+    }
+
+    const float third = 1.0f / 3.0f;
+    const float r3 = rho * third;
+    const lbm_v2 RU = rho * U;
+    const float ruz = rho * uz;
+    lbm_v2 P = M - RU * U;                // (Pxx, Pyy)
+    P = P - r3;
+    const float Pzz = mzz - ruz * uz - r3;
+    const float Pxy = mxy - RU.x * U.y;
+    const lbm_v2 Pq = D - lbm_v2{ruz * U.x, RU.y * uz};   // (Pzx, Pyz)
+
+    const float trace = P.x + P.y + Pzz;
+    const float corr = (trace * third) * (omega_shear - omega_bulk);
+    const float oms = 1.0f - omega_shear;
+    const lbm_v2 N = P * oms + corr;      // (Nxx, Nyy)
+    const float Nzz = Pzz * oms + corr;
+    const float txy = 2.0f * (Pxy * oms);
+    const lbm_v2 T = 2.0f * (Pq * oms);   // (tzx, tyz)
+
+    const float QA = 1.0f - third;
+    const float QB = 0.0f - third;
+    const lbm_v2 A = QA * N, B = QB * N;
+    const float Az = QA * Nzz, Bz = QB * Nzz;
+    const float bxby = B.x + B.y;
+    const lbm_v2 ab = {A.x + B.y, B.x + A.y};             // (axby, bxay)
+    const float d000 = bxby + Bz;
+    const lbm_v2 d1 = ab + Bz;            // (d100, d010)
+    const float d001 = bxby + Az;
+    const float d110 = (A.x + A.y) + Bz;
+    const lbm_v2 d2 = ab + Az;            // (d101, d011)
+
+    const float c0 = 4.5f * W0, c1 = 4.5f * W1, c2 = 4.5f * W2;
+    const float w0r = W0 * rho, w1r = W1 * rho, w2r = W2 * rho;
+    const lbm_v2 UU = U * U;
+    const float usq = UU.x + UU.y + uz * uz;
+    const float c15 = 1.5f * usq;
+
+    out[0] = w0r * (1.0f - c15) + c0 * d000;
+
+// (3 cu, -3 cu) as cu * (3, -3): the negated product is the product negated, exactly
+    const lbm_v2 pm3 = {3.0f, -3.0f};
+#define LBM_PAIR2(KP, KM, CU, B_, WR, NEQ)   \
+    {                                        \
+        lbm_v2 t = lbm_v2{(CU), (CU)} * pm3; \
+        t = 1.0f + t;                        \
+        t = t + (B_);                        \
+        t = t - c15;                         \
+        t = (WR) * t;                        \
+        t = t + (NEQ);                       \
+        out[KP] = t.x;                       \
+        out[KM] = t.y;                       \
+    }
+    {   // k = 1..4: cu = (ux, uy)
+        const lbm_v2 b = 4.5f * U * U, q = c1 * d1;
+        LBM_PAIR2(1, 2, U.x, b.x, w1r, q.x)
+        LBM_PAIR2(3, 4, U.y, b.y, w1r, q.y)
+    }
+    {   // k = 5, 6
+        const float b = 4.5f * uz * uz, q = c1 * d001;
+        LBM_PAIR2(5, 6, uz, b, w1r, q)
+    }
+    const lbm_v2 zpm = lbm_v2{uz, uz} * lbm_v2{1.0f, -1.0f};   // (uz, -uz)
+    {   // k = 7..10: cu = ux +- uy
+        const lbm_v2 cu = lbm_v2{U.x, U.x} + lbm_v2{U.y, U.y} * lbm_v2{1.0f, -1.0f};
+        const lbm_v2 b = 4.5f * cu * cu, q = c2 * (lbm_v2{d110, d110} + lbm_v2{txy, txy} * lbm_v2{1.0f, -1.0f});
+        LBM_PAIR2(7, 8, cu.x, b.x, w2r, q.x)
+        LBM_PAIR2(9, 10, cu.y, b.y, w2r, q.y)
+    }
+    const lbm_v2 Tx = lbm_v2{T.x, T.x} * lbm_v2{1.0f, -1.0f}, Ty = lbm_v2{T.y, T.y} * lbm_v2{1.0f, -1.0f};
+    {   // k = 11..14: cu = ux +- uz
+        const lbm_v2 cu = lbm_v2{U.x, U.x} + zpm;
+        const lbm_v2 b = 4.5f * cu * cu, q = c2 * (lbm_v2{d2.x, d2.x} + Tx);
+        LBM_PAIR2(11, 12, cu.x, b.x, w2r, q.x)
+        LBM_PAIR2(13, 14, cu.y, b.y, w2r, q.y)
+    }
+    {   // k = 15..18: cu = uy +- uz
+        const lbm_v2 cu = lbm_v2{U.y, U.y} + zpm;
+        const lbm_v2 b = 4.5f * cu * cu, q = c2 * (lbm_v2{d2.y, d2.y} + Ty);
+        LBM_PAIR2(15, 16, cu.x, b.x, w2r, q.x)
+        LBM_PAIR2(17, 18, cu.y, b.y, w2r, q.y)
+    }
+#undef LBM_PAIR2
+}
+#endif
+
 }  // namespace d3q19

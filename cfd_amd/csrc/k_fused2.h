@@ -25,6 +25,13 @@
 // fused_pair() in lbm_hip.hip).  The arithmetic per cell is moments_of() + collide_cell() on the same
 // operands in the same order as two single steps, so results are bit-identical (tests/test_fused_gpu.py).
 
+// LBM_F2_SCALAR_COLLIDE: the scalar moments_of() + collide_cell() instead of collide_packed() (same bits)
+#ifdef LBM_F2_SCALAR_COLLIDE
+#define F2_COLLIDE(IN, OUT) { const Moments m_ = moments_of(IN); collide_cell(IN, m_, p.omega_shear, p.omega_bulk, OUT); }
+#else
+#define F2_COLLIDE(IN, OUT) collide_packed(IN, p.omega_shear, p.omega_bulk, OUT)
+#endif
+
 struct FusedGrid {
     int nbx, nby, nbz;      // 64-cell tiles in x, TY-row tiles in y, pieces an unobstructed tile column is cut into in z
     int nblocks;            // blocks = workgroups of a launch
@@ -220,8 +227,7 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
                 F2<PRESET, Q - 1>::load(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, pf);
             }
             F2<PRESET, Q - 1>::fix_inlet(xl, inlet_e, pf);
-            const Moments m = moments_of(pf);
-            collide_cell(pf, m, p.omega_shear, p.omega_bulk, above);
+            F2_COLLIDE(pf, above);
         }
         if (STAGE) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area has been read: refill it
@@ -238,8 +244,7 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
             if (second) {
                 float f[Q], o[Q];
                 F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, below, cur, above, f);
-                const Moments m = moments_of(f);
-                collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
+                F2_COLLIDE(f, o);
                 // the staged loads have had the whole second step to land; waiting for them HERE keeps the
                 // latency of the stores below out of the next iteration (stores count in vmcnt too)
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -613,6 +613,18 @@ static int fused_prepare(lbm_ctx* c) {
             fused_cells += (long long)std::min(64, g.W - r.bx * 64) * tyn * n;
         }
     }
+    if (getenv("LBM_FUSED_DEBUG")) {   // planning summary for tools/fused_bench.py
+        long long f0 = 0, f1 = 0, f2 = 0;
+        for (long long i = 0; i < ntiles; i++) { f0 += fl[(size_t)i] == 0; f1 += fl[(size_t)i] == 1; f2 += fl[(size_t)i] == 2; }
+        fprintf(stderr, "[fused] %dx%dx%d TY %d rows [%d,%d) layers [%d,%d) tiles: %lld interior %lld boundary %lld solid; %zu runs, zchunk %d, %zu blocks, fused %.1f %% of cells\n",
+                g.W, g.H, g.D, TY, fg.y_first, fg.y_end, fg.zl_first, fg.zl_end, f0, f1, f2, runs.size(), zchunk, all.size(),
+                100.0 * (double)fused_cells / (double)cells(c));
+        std::vector<long long> per_by((size_t)fg.nby, 0);
+        for (const Run& r : runs) per_by[(size_t)r.by] += r.len;
+        for (int by = 0; by < fg.nby; by++)
+            fprintf(stderr, "[fused]   y tile %d (rows %d..): %.1f %% of its column-layers\n", by, fg.y_first + by * TY,
+                    100.0 * (double)per_by[(size_t)by] / ((double)fg.nbx * (fg.zl_end - fg.zl_first)));
+    }
     if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
     // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
     // (and the contiguous ranges the XCDs take, k_fused2.h) are neighbours in space; long blocks first within
