@@ -34,16 +34,13 @@
 
 struct FusedGrid {
     int nbx, nby, nbz;      // 64-cell tiles in x, TY-row tiles in y, pieces an unobstructed tile column is cut into in z
-    int nblocks;            // blocks = workgroups of a launch
+    int nblocks;            // workgroups of a launch: 8 x the longest of the eight XCD ranges of the block list
     int y_first, y_end;     // rows [y_first, y_end) take the fused path (y_first >= 2, y_end <= H - 2)
     int zl_first, zl_end;   // local layers (ghost offset included) the blocks lie in: [3, D - 1)
     int zchunk;             // most layers a block takes
 };
 
 constexpr int F2_LCOLS = 66;   // 64 cells + one halo column each side
-#ifndef F2_XCD_REMAP
-#define F2_XCD_REMAP 1
-#endif
 // LDS plane of an exchanged population: 0..3 up-going oblique (11,14,15,18), 4..11 in-plane (1,2,3,4,7,8,9,10),
 // 12..15 down-going oblique (12,13,16,17); -1: own column (0, 5, 6), stays in registers
 __host__ __device__ constexpr int f2_plane(int k) {
@@ -74,33 +71,72 @@ __device__ __forceinline__ int f2_role(int wave) {   // 0 .. TY+1: row of the ha
 // (offm: one float to the left for the outlet lane x = W-1, whose cx = -1 directions copy from x = W-1).
 template <int PRESET, int K>
 __device__ __forceinline__ const float* f2_src(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                               bool xl, bool xr) {
+                                               bool xl, bool xr, bool bb) {
     constexpr int cx = CX[K];
     const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row - cx) * 4;
-    if (cx == 0) return reinterpret_cast<const float*>(base + dk + off);
-    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF)
-        return reinterpret_cast<const float*>(base + dk + (cx == -1 ? offm : off));
-    // cavity: the wall lane reads its own cell's opposite population
+    // bounce-back (a cavity wall, or with OBST a solid neighbour): the own cell's opposite population
     const long long dw = (long long)INV[K] * g.plane * 4;
+    const unsigned delta = (unsigned)(int)(dw - dk);              // exact in 32 bits: |dw - dk| < 2 layers (checked on the host)
+    if (cx == 0) return reinterpret_cast<const float*>(base + dk + (bb ? off + delta : off));
+    if (PRESET == LBM_PRESET_WIND_TUNNEL_REF)
+        return reinterpret_cast<const float*>(base + dk + (bb ? off + delta : (cx == -1 ? offm : off)));
     const bool wall = cx == 1 ? xl : xr;
-    const unsigned delta = (unsigned)(int)(dw - dk);          // exact in 32 bits: |dw - dk| < 2 layers (checked on the host)
-    return reinterpret_cast<const float*>(base + dk + (wall ? off + delta : off));
+    return reinterpret_cast<const float*>(base + dk + ((wall || bb) ? off + delta : off));
+}
+
+// OBST: which directions of a cell bounce back from a solid neighbour (bit k; lbm_solver.cu:298-318 via
+// classify_with() in k_step.h; bit 0: the cell itself is solid) -- one 32-bit word per cell, computed once per
+// mask change by k_f2_nb_words into an array laid out like one population of the planes layout ([zl][y][x],
+// row pitch Wp, ghost layers included).  The fused kernel reads the word of a cell two layers ahead of its
+// use (4 B per cell and pass beside the 152 B of the populations), so that no wave ever waits for the mask:
+// a first version that walked the packed mask's nine rows per flagged tile inside the layer loop stalled its
+// whole workgroup at the barrier for the latency of those loads (36 GLUPS inside the kernel instead of 57).
+template <int K>
+struct F2Nb {
+    static __device__ __forceinline__ unsigned cell(const Geo& g, const unsigned long long* __restrict__ mask, int x, int y, int zl) {
+        const int nx = x - CX[K], ny = y - CY[K];
+        unsigned m = F2Nb<K - 1>::cell(g, mask, x, y, zl);
+        if (nx >= 0 && nx < g.W && ny >= 0 && ny < g.H) m |= (unsigned)solid_at(g, mask, nx, ny, zl - CZ[K]) << K;
+        return m;
+    }
+};
+template <>
+struct F2Nb<0> {
+    static __device__ __forceinline__ unsigned cell(const Geo& g, const unsigned long long* __restrict__ mask, int x, int y, int zl) {
+        return (unsigned)solid_at(g, mask, x, y, zl);
+    }
+};
+__global__ __launch_bounds__(256) void k_f2_nb_words(const unsigned long long* __restrict__ mask, unsigned* __restrict__ nbw, Geo g) {
+    const long long i = gidx();                       // over the owned layers zl = 1 .. D
+    const long long n = (long long)g.D * g.H * g.Wp;
+    if (i >= n) return;
+    const int x = (int)(i % g.Wp);
+    const int y = (int)((i / g.Wp) % g.H);
+    const int zl = (int)(i / ((long long)g.Wp * g.H)) + 1;
+    nbw[(long long)g.H * g.Wp + i] = x < g.W ? F2Nb<Q - 1>::cell(g, mask, x, y, zl) : 0u;
+}
+
+// direction K of a cell bounces back from a solid neighbour; the outlet branch (x = W-1, cx = -1) comes before
+// the solid test in the reference chain
+template <int K>
+__device__ __forceinline__ bool f2_bb(unsigned nb, bool xr) {
+    return ((nb >> K) & 1u) && !(CX[K] == -1 && xr);
 }
 
 template <int PRESET, int K>
 struct F2 {
     // issue the first-step loads of one layer into the wave's staging area (LDS-DMA)
     static __device__ __forceinline__ void issue(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                                 bool xl, bool xr, float* stage) {
-        F2<PRESET, K - 1>::issue(base, g, off, offm, xl, xr, stage);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K>(base, g, off, offm, xl, xr),
+                                                 bool xl, bool xr, unsigned nb, float* stage) {
+        F2<PRESET, K - 1>::issue(base, g, off, offm, xl, xr, nb, stage);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)),
                                          (__attribute__((address_space(3))) void*)(stage + K * 64), 4, 0, 0);
     }
     // the same loads straight into registers (no prefetch)
     static __device__ __forceinline__ void load(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                                bool xl, bool xr, float* f) {
-        F2<PRESET, K - 1>::load(base, g, off, offm, xl, xr, f);
-        f[K] = ldk<1, K>(f2_src<PRESET, K>(base, g, off, offm, xl, xr));
+                                                bool xl, bool xr, unsigned nb, float* f) {
+        F2<PRESET, K - 1>::load(base, g, off, offm, xl, xr, nb, f);
+        f[K] = ldk<1, K>(f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)));
     }
     // staged values -> registers; the inlet lane's cx = +1 directions are the constant inlet equilibrium
     static __device__ __forceinline__ void unstage(const float* stage, int lane, bool xl, float inlet_e, float* f) {
@@ -122,39 +158,45 @@ struct F2 {
     // second step, one direction: the streamed population of cell (col, r) of the tile, with the x ends of
     // the domain handled as in the first step (slotm: the outlet lane reads its own column)
     template <int PLANE>
-    static __device__ __forceinline__ void get(const float* exch, int slot, int slotm, bool xl, bool xr, float inlet_e,
+    static __device__ __forceinline__ void get(const float* exch, int slot, int slotm, bool xl, bool xr, float inlet_e, unsigned nb,
                                                const float* below, const float* cur, const float* above, float* f) {
-        F2<PRESET, K - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, below, cur, above, f);
+        F2<PRESET, K - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb, below, cur, above, f);
         constexpr int pl = f2_plane(K);
         constexpr int cx = CX[K];
+        const bool bb = f2_bb<K>(nb, xr);     // solid neighbour: the own cell's opposite population of the same layer
         if (pl < 0) {
-            f[K] = K == 0 ? cur[0] : (K == 5 ? below[5] : above[6]);
+            const float v = K == 0 ? cur[0] : (K == 5 ? below[5] : above[6]);
+            f[K] = (K != 0 && bb) ? cur[INV[K]] : v;
         } else if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
             const float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + (cx == -1 ? slotm : slot)];
-            f[K] = (cx == 1 && xl) ? weight(K) * inlet_e : v;
+            f[K] = (cx == 1 && xl) ? weight(K) * inlet_e : (bb ? cur[INV[K]] : v);
         } else {
             const float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + slot];
             const bool wall = cx == 1 ? xl : (cx == -1 ? xr : false);
-            f[K] = wall ? cur[INV[K]] : v;    // wall bounce-back: the own cell's opposite population of the same layer
+            f[K] = (wall || bb) ? cur[INV[K]] : v;    // wall bounce-back likewise
         }
     }
 };
 template <int PRESET>
 struct F2<PRESET, -1> {
-    static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, float*) {}
-    static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, float*) {}
+    static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*) {}
+    static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*) {}
     static __device__ __forceinline__ void unstage(const float*, int, bool, float, float*) {}
     static __device__ __forceinline__ void fix_inlet(bool, float, float*) {}
     template <int PLANE> static __device__ __forceinline__ void put(float*, int, const float*, const float*, const float*) {}
-    template <int PLANE> static __device__ __forceinline__ void get(const float*, int, int, bool, bool, float, const float*,
+    template <int PLANE> static __device__ __forceinline__ void get(const float*, int, int, bool, bool, float, unsigned, const float*,
                                                                     const float*, const float*, float*) {}
 };
 
 // TY: rows per tile.  STAGE 1: the next layer's loads are prefetched into LDS; 0: loaded when needed.
 // NBUF 2: two exchange buffers, one barrier per layer; 1: one buffer, two barriers per layer.
-template <int PRESET, int TY, int STAGE, int NBUF>
+// OBST 1: blocks may hold solid cells (an obstacle; not the walls of the domain): directions that would pull
+// from a solid cell bounce back (first step: the load address; second step: the own first-step result), solid
+// cells are computed like any other and never stored.
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST>
 __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
-                                                          const unsigned long long* __restrict__ blocks, Geo g, Params p,
+                                                          const unsigned long long* __restrict__ blocks,
+                                                          const unsigned* __restrict__ nbw, Geo g, Params p,
                                                           FusedGrid fg) {
     constexpr int ROWS = TY + 2;
     constexpr int PLANE = ROWS * F2_LCOLS;
@@ -169,9 +211,13 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     // still gets the same number of blocks whatever the obstacles leave eligible.
     int bx, by, zs, ze;                                          // second step: local layers [zs, ze)
     {
-        const unsigned total = gridDim.x, launch = blockIdx.x;
-        const unsigned xcd = launch & 7u, nth = launch >> 3, q = total >> 3, r = total & 7u;
-        const unsigned long long e = blocks[F2_XCD_REMAP ? xcd * q + min(xcd, r) + nth : launch];
+        // blocks[0..8]: where each XCD's range of the list starts (ranges of equal WORK, not equal count: the
+        // runs an obstacle leaves differ in length); workgroup n of XCD x takes entry n of range x, a workgroup
+        // beyond its range has nothing to do
+        const unsigned xcd = blockIdx.x & 7u, nth = blockIdx.x >> 3;
+        const unsigned first = (unsigned)blocks[xcd], end = (unsigned)blocks[xcd + 1];
+        if (nth >= end - first) return;
+        const unsigned long long e = blocks[9 + first + nth];
         // the entry is the same for the whole workgroup: keep what is derived from it in scalar registers
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
         bx = (int)(lo & 0xfffu);
@@ -208,50 +254,65 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     const unsigned cell_b = (unsigned)(((long long)(active ? y : y0) * g.row + (active ? x : x0)) * 4);
     auto off_of = [&](int L) { return (unsigned)(L - (zs - 3)) * layer_b + cell_b; };
 
+    // solid-neighbour bits of the lane's cell in layer L (0 without OBST: everything below folds away)
+    const unsigned nb_cell = (unsigned)((active ? y : y0) * g.Wp + (active ? x : x0));
+    const unsigned* nb_base = nbw + (long long)(zs - 3) * g.H * g.Wp;
+    auto nb_of = [&](int L) -> unsigned {
+        if (!OBST || !active) return 0u;
+        return nb_base[(unsigned)(L - (zs - 3)) * (unsigned)(g.H * g.Wp) + nb_cell];
+    };
+
     float below[Q], cur[Q], above[Q], pf[Q];   // first-step results of layers L-2, L-1, L; the loads of layer L
 #pragma unroll
     for (int k = 0; k < Q; k++) { below[k] = 0.f; cur[k] = 0.f; above[k] = 0.f; pf[k] = 0.f; }
+    // bits of layers L-1, L, L+1: loaded two layers before the first use (the addresses of the first-step loads)
+    unsigned nb_cur = 0u, nb_above = nb_of(zs - 1), nb_next = nb_of(zs);
     if (STAGE) {
         const unsigned off = off_of(zs - 1);
-        if (active) F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, stage);
+        if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
+            F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     int buf = 0;
     for (int L = zs - 1; L <= ze; L++) {
         // ---- first step of layer L ---------------------------------------------------------------------
-        if (active) {
+        // (OBST: a wave whose cells of this layer are all solid neither loads nor collides: wave-uniform)
+        if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
             if (STAGE) {
                 F2<PRESET, Q - 1>::unstage(stage, lane, xl, inlet_e, pf);
             } else {
                 const unsigned off = off_of(L);
-                F2<PRESET, Q - 1>::load(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, pf);
+                F2<PRESET, Q - 1>::load(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, pf);
             }
             F2<PRESET, Q - 1>::fix_inlet(xl, inlet_e, pf);
             F2_COLLIDE(pf, above);
         }
         if (STAGE) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area has been read: refill it
-            if (active && L < ze) {
+            if (active && L < ze && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
                 const unsigned off = off_of(L + 1);
-                F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, stage);
+                F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage);
             }
         }
+        const unsigned nb_next2 = L + 2 <= ze ? nb_of(L + 2) : 0u;
         // ---- second step of layer L - 1 ------------------------------------------------------------------
         if (L >= zs + 1) {
             float* exch = lds + buf * EXCH;
             if (active) F2<PRESET, Q - 1>::template put<PLANE>(exch, slot, below, cur, above);
             __syncthreads();
-            if (second) {
+            if (second && (!OBST || __ballot(second && !(nb_cur & 1u)) != 0ull)) {
                 float f[Q], o[Q];
-                F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, below, cur, above, f);
+                F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb_cur, below, cur, above, f);
                 F2_COLLIDE(f, o);
                 // the staged loads have had the whole second step to land; waiting for them HERE keeps the
                 // latency of the stores below out of the next iteration (stores count in vmcnt too)
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned offo = off_of(L - 1);
+                if (!OBST || !(nb_cur & 1u)) {
 #pragma unroll
-                for (int k = 0; k < Q; k++)   // one base, 32-bit offsets: population k sits k planes further on
-                    __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (offo + (unsigned)k * plane_b)));
+                    for (int k = 0; k < Q; k++)   // one base, 32-bit offsets: population k sits k planes further on
+                        __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (offo + (unsigned)k * plane_b)));
+                }
             } else {
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -261,5 +322,6 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) { below[k] = cur[k]; cur[k] = above[k]; }
+        nb_cur = nb_above; nb_above = nb_next; nb_next = nb_next2;
     }
 }

@@ -116,6 +116,9 @@ struct lbm_ctx {
     bool fused_usable = false;     // ... and enough of the domain takes the fused path for it to pay
     int f2_ty = 12, f2_stage = 1, f2_nbuf = 1;  // kernel variant: measured best of the compiled ones (profiles/r02_tuning.md) (LBM_FUSED_VARIANT="TY,STAGE,NBUF")
     int f2_zsplit = 0;             // LBM_FUSED_ZSPLIT: z chunks per tile column (0 = chosen by fused_prepare)
+    bool f2_obst = true;           // LBM_FUSED_OBST=0: blocks keep clear of obstacles (round-2 first form)
+    bool f2_obst_blocks = false;   // some block of the current list holds or touches solid cells
+    unsigned* f2_nbw = nullptr;    // one word per cell: which directions bounce back from a solid neighbour (k_f2_nb_words)
     FusedGrid fg{};
     float* ft = nullptr;           // third population buffer: holds time t+1 on the rim between its two steps
     unsigned long long* f2_blocks = nullptr;   // the blocks (x tile | y tile << 12 | first layer << 24 | layers << 44), one workgroup of k_fused2 each
@@ -127,6 +130,7 @@ struct lbm_ctx {
     hipStream_t stream_rim = nullptr;   // library-owned side stream: the rim's two small launches run beside k_fused2
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
     bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
+    int f2_overlap_pct = 15;       // LBM_FUSED_OVERLAP_PCT: side stream when the rim is more than this share of the cells
     bool f2_rim_pending = false;   // the side stream holds rim launches the context's stream has not waited for yet
     // a PAIR of steps on a z-slab (lbm_pair_*): 0 idle, 1 boundary layers of the first step issued, 2 interior issued,
     // 3 boundary layers of the second step issued
@@ -453,10 +457,10 @@ static bool fused_applies_slab(const lbm_ctx* c) {   // lbm_pair_*() on a z-slab
 struct F2Variant { int ty, stage, nbuf; };
 static const F2Variant kF2Variants[] = {{9, 1, 2}, {12, 1, 1}, {13, 1, 1}, {9, 0, 2}, {12, 0, 2}};
 
-template <int PRESET, int TY, int STAGE, int NBUF>
-static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout) {
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST>
+static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout) {
     static bool attr_set[MAX_DEVICES] = {false};
-    auto kern = k_fused2<PRESET, TY, STAGE, NBUF>;
+    auto kern = k_fused2<PRESET, TY, STAGE, NBUF, OBST>;
     const size_t lds = f2_lds_bytes(TY, STAGE, NBUF);
     if (!attr_set[c->device]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -464,8 +468,14 @@ static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout
         attr_set[c->device] = true;
     }
     hipLaunchKernelGGL(kern, dim3(c->fg.nblocks), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
-                       c->g, c->p, c->fg);
+                       c->f2_nbw, c->g, c->p, c->fg);
     return hipGetLastError();
+}
+template <int PRESET, int TY, int STAGE, int NBUF>
+static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout) {
+    // blocks that hold solid cells need the bounce-back form of the kernel; a domain without obstacles keeps the plain one
+    return c->f2_obst_blocks ? launch_fused_kernel<PRESET, TY, STAGE, NBUF, 1>(c, fin, fout)
+                             : launch_fused_kernel<PRESET, TY, STAGE, NBUF, 0>(c, fin, fout);
 }
 template <int TY, int STAGE, int NBUF>
 static hipError_t launch_fused_preset(lbm_ctx* c, const float* fin, float* fout) {
@@ -531,42 +541,77 @@ static int fused_prepare(lbm_ctx* c) {
     };
     FusedGrid fg;
     fg.nbx = g.Wt;
+    // (with f2_obst the kernel bounces back from the floor's solid cells like from any other: no shift)
     fg.y_first = 2;
-    while (fg.y_first < std::min(g.H / 4, 8) && !row_clean(fg.y_first - 1)) fg.y_first++;
+    while (!c->f2_obst && fg.y_first < std::min(g.H / 4, 8) && !row_clean(fg.y_first - 1)) fg.y_first++;
     fg.y_end = g.H - 2;
-    while (fg.y_end > g.H - std::min(g.H / 4, 8) && !row_clean(fg.y_end)) fg.y_end--;
+    while (!c->f2_obst && fg.y_end > g.H - std::min(g.H / 4, 8) && !row_clean(fg.y_end)) fg.y_end--;
     if (fg.y_end - fg.y_first < 1) return LBM_OK;
     fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
     if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 bits for the y tile
     fg.zl_first = g.slab ? 2 : 3;                                   // widest possible range of second-step layers:
     fg.zl_end = g.slab ? g.D : g.D - 1;                             // a slab's outer layers are its boundary layers, a domain's its walls
 
-    // Runs: for every tile column (x tile, y tile) the maximal runs of layers in which every tile the first step
-    // touches -- one more tile in x and one more row in y on every side -- is an interior tile (flag 0).  A run of
-    // clean layers [a, b] carries second steps for the layers a+1 .. b-1.
+    // Runs: for every tile column (x tile, y tile) the maximal runs of layers a block can take.  Everything the
+    // first step touches -- one more tile in x, one more row in y and one more layer in z on every side -- must
+    // be free of the domain's walls (the kernel has no wall rows / layers; rows are kept off them by y_first /
+    // y_end).  Obstacles: with f2_obst the kernel bounces back from solid cells itself, so flagged and all-solid
+    // tiles may lie inside a block (but for the wind tunnel's outlet tile column, whose outlet branch may copy
+    // from a solid cell's frozen values); without it every tile in reach must be an interior tile (flag 0).
+    // A run of usable layers [a, b] carries second steps for the layers a+1 .. b-1; layers in which most of the
+    // block is solid are not worth a pass and end a run as well.
     constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
     struct Run { int bx, by, a, len; };
     std::vector<std::vector<Run>> runs_of((size_t)fg.nby);
+    std::vector<unsigned char> touches((size_t)fg.nby, 0);
+    const bool obst = c->f2_obst;
+    const int wanted_pct = getenv("LBM_FUSED_WANTED") ? atoi(getenv("LBM_FUSED_WANTED")) : 34;   // experiment knob
 #pragma omp parallel for schedule(dynamic, 1)
     for (int by = 0; by < fg.nby; by++) {
         const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
         for (int bx = 0; bx < fg.nbx; bx++) {
+            const bool outlet_tile = c->preset == LBM_PRESET_WIND_TUNNEL_REF && bx == g.Wt - 1;
             auto clean = [&](int z) {
                 for (int y = y0 - 1; y <= y0 + tyn; y++)
                     for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
                         if (fl[tile(xs, y, z)] != 0) return false;
                 return true;
             };
+            auto usable = [&](int z) {   // as a layer of first steps
+                if (!obst || outlet_tile) return clean(z);
+                const int zg = z + g.z0;
+                return zg > 0 && zg < g.Dg - 1;
+            };
+            auto wanted = [&](int z) {   // as a layer of second steps
+                if (!obst || outlet_tile) return true;
+                int fluid = 0;
+                for (int y = y0; y < y0 + tyn; y++) fluid += fl[tile(bx, y, z)] != 2;
+                return fluid * 100 >= tyn * wanted_pct;
+            };
             int z = 0;
             while (z < g.D) {
-                if (!clean(z)) { z++; continue; }
+                if (!usable(z)) { z++; continue; }
                 const int a = z;
-                while (z < g.D && clean(z)) z++;
-                const int len = (z - 1) - a - 1;                     // clean layers [a, z-1] (0-based): second steps a+1 .. z-2
-                if (len >= MIN_LAYERS) runs_of[(size_t)by].push_back({bx, by, a, len});
+                while (z < g.D && usable(z)) z++;
+                const int b = z - 1;                                 // usable layers [a, b] (0-based): second steps a+1 .. b-1
+                int s = a + 1;
+                while (s <= b - 1) {
+                    if (!wanted(s)) { s++; continue; }
+                    int e = s;
+                    while (e + 1 <= b - 1 && wanted(e + 1)) e++;
+                    if (e - s + 1 >= MIN_LAYERS) {
+                        runs_of[(size_t)by].push_back({bx, by, s - 1, e - s + 1});
+                        if (obst && !touches[(size_t)by])
+                            for (int zz = s - 1; zz <= e + 1 && !touches[(size_t)by]; zz++)
+                                if (!clean(zz)) touches[(size_t)by] = 1;
+                    }
+                    s = e + 1;
+                }
             }
         }
     }
+    c->f2_obst_blocks = false;
+    for (unsigned char t : touches) c->f2_obst_blocks = c->f2_obst_blocks || t;
     std::vector<Run> runs;
     for (auto& v : runs_of) runs.insert(runs.end(), v.begin(), v.end());
     if (runs.empty()) return LBM_OK;
@@ -635,11 +680,30 @@ static int fused_prepare(lbm_ctx* c) {
         if (p.by != q.by) return p.by < q.by;
         return p.bx < q.bx;
     });
-    std::vector<unsigned long long> blocks;
-    blocks.reserve(all.size());
+    // Eight contiguous ranges of the list, one per XCD, of equal work (a block costs its layers + the two lead-in
+    // layers); within a range the long blocks go first so that the short ones fill the tail.  Without obstacles
+    // all blocks are alike and this is the list cut into eight equal parts in its own order.
+    std::vector<unsigned long long> blocks(9, 0ull);
+    {
+        long long total = 0;
+        for (const Block& k : all) total += k.len + 2;
+        size_t at = 0;
+        long long done = 0;
+        size_t longest = 0;
+        for (int xcd = 0; xcd < 8; xcd++) {
+            const size_t first = at;
+            const long long target = total * (xcd + 1) / 8;
+            while (at < all.size() && (xcd == 7 || done + (long long)(all[at].len + 2) / 2 <= target)) { done += all[at].len + 2; at++; }
+            std::stable_sort(all.begin() + (long)first, all.begin() + (long)at, [](const Block& p, const Block& q) { return p.len > q.len; });
+            blocks[(size_t)xcd] = first;
+            blocks[(size_t)xcd + 1] = at;
+            longest = std::max(longest, at - first);
+        }
+        fg.nblocks = (int)(8 * longest);
+    }
+    blocks.reserve(9 + all.size());
     for (const Block& k : all)
         blocks.push_back((unsigned long long)k.bx | ((unsigned long long)k.by << 12) | ((unsigned long long)k.zs << 24) | ((unsigned long long)k.len << 44));
-    fg.nblocks = (int)blocks.size();
 
     // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
     // t+1 values from the 26 neighbouring tiles, so the first rim step covers the rim dilated by one tile
@@ -677,6 +741,17 @@ static int fused_prepare(lbm_ctx* c) {
     for (auto& l : list)
         while (l.size() % 4) l.push_back(~0ull);
 
+    if (c->f2_obst_blocks) {   // the solid-neighbour words of every cell (k_fused2.h); without them the blocks must keep clear of obstacles
+        const size_t words = (size_t)(g.D + 2) * g.H * g.Wp;
+        if (!c->f2_nbw && hipMalloc(&c->f2_nbw, words * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->f2_nbw = nullptr; c->f2_obst = false; c->fused_ready = false;
+            return fused_prepare(c);
+        }
+        HIPCHK(c, hipMemsetAsync(c->f2_nbw, 0, words * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(k_f2_nb_words, grid1((long long)g.D * g.H * g.Wp), dim3(256), 0, c->stream, c->mask, c->f2_nbw, c->g);
+        HIPCHK(c, hipGetLastError());
+    }
     if (!c->ft) {  // third buffer; without it the fused path stays off
         if (hipMalloc(&c->ft, c->pop_bytes) != hipSuccess) { (void)hipGetLastError(); c->ft = nullptr; return LBM_OK; }
         hipLaunchKernelGGL(k_sync_solid, grid1(cells(c)), dim3(256), 0, c->stream, c->f[c->cur], c->ft, c->mask, c->g);
@@ -724,7 +799,7 @@ static int fused_pair(lbm_ctx* c, bool first) {
     hipStream_t rim_stream = c->stream;
     // worth it when the rim is a good part of the domain (obstacles: +3 % at 512x256x256 + car); around an empty
     // box the two small launches cost the same beside the fused kernel as behind it
-    const bool overlap = c->f2_overlap && c->rim_cells * 100 > cells(c) * 15;
+    const bool overlap = c->f2_overlap && c->rim_cells * 100 > cells(c) * c->f2_overlap_pct;
     if (overlap) {
         if (!c->stream_rim) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
@@ -940,7 +1015,9 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->fused_on = o.two_step != LBM_TWO_STEP_OFF;
     if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
+    if (const char* t = getenv("LBM_FUSED_OBST")) c->f2_obst = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_OVERLAP")) c->f2_overlap = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_OVERLAP_PCT")) c->f2_overlap_pct = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_VARIANT")) {
         int ty = 0, st = 0, nb = 0;
         bool known = false;
@@ -1024,7 +1101,7 @@ int lbm_destroy(lbm_ctx* c) {
     if (!c->f1_in_alloc0) hipFree(c->f[1]);
     hipFree(c->mask); hipFree(c->flags);
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
-    hipFree(c->ft); hipFree(c->f2_blocks); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
+    hipFree(c->ft); hipFree(c->f2_nbw); hipFree(c->f2_blocks); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
     for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
     if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
     if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);

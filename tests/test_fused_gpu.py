@@ -144,3 +144,49 @@ def test_fused_equals_single_steps_256(lbm):
     np.testing.assert_array_equal(a.velocity(), b.velocity())
     fa, fb = a.populations(), b.populations()
     assert np.array_equal(fa, fb)
+
+
+def test_fused_blocks_hold_obstacles(oracle, lbm, monkeypatch):
+    """blocks run THROUGH obstacles (the kernel bounces back from solid cells itself, solid cells are never
+    stored): a thin plate, a staircase, a box touching the floor, single cells; with LBM_FUSED_OBST=0 the
+    blocks keep clear of them as in the first form of the path.  Both must equal the oracle bit for bit."""
+    W, H, D = 200, 52, 40
+    covered = {}
+    for obst in ("1", "0"):
+        monkeypatch.setenv("LBM_FUSED_OBST", obst)
+        for preset in (0, 1):
+            o = oracle.Solver(W, H, D, preset)
+            g = lbm.Solver(W, H, D, preset)
+            for s in (o, g):
+                s.init()
+                s.add_solid(60, 10, 8, 1, 30, 20)          # plate one cell thick across the flow
+                s.add_solid(100, 0, 12, 30, 9, 14)         # box on the floor over a tile border in x
+                for i in range(8):                          # staircase: diagonal neighbours only
+                    s.add_solid(150 + i, 20 + i, 15 + i, 1, 1, 1)
+                s.add_solid(63, 25, 20, 1, 1, 1)            # single cell at a tile's last column / next tile's first
+                s.add_solid(64, 27, 22, 1, 1, 1)
+            o.step(11); g.step(11)
+            same(o, g, f"LBM_FUSED_OBST={obst}, preset {preset}")
+            if fused_in_use(lbm, g, may_decline=obst == "0"):
+                covered[(obst, preset)] = g.stats()["fused_cells"]
+            o.step(4); g.step(4)                            # again from the state the fused path left
+            same(o, g, f"LBM_FUSED_OBST={obst}, preset {preset}, second call")
+    for preset in (0, 1):
+        if ("1", preset) in covered:
+            assert covered[("1", preset)] > covered.get(("0", preset), 0)
+
+
+def test_fused_equals_single_steps_car_512(lbm):
+    """BASELINE.json configs[2] at full size (512x256x256 wind tunnel around the voxelised car stand-in):
+    13 steps with blocks through the car against 13 single steps"""
+    import os
+    car = os.path.join(os.path.dirname(__file__), "golden", "car_like.obj")
+    a = lbm.Solver(512, 256, 256, two_step=lbm.TWO_STEP_OFF)
+    b = lbm.Solver(512, 256, 256)
+    for s in (a, b):
+        s.init(); s.load_mesh(car); s.step(13)
+    if fused_in_use(lbm, b):
+        assert b.stats()["fused_cells"] > 0.7 * 512 * 256 * 256
+    np.testing.assert_array_equal(a.density(), b.density())
+    np.testing.assert_array_equal(a.velocity(), b.velocity())
+    assert np.array_equal(a.populations(), b.populations())
