@@ -291,7 +291,9 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area has been read: refill it
             if (active && L < ze && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
                 const unsigned off = off_of(L + 1);
-                F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage);
+                // (most waves have no solid cell in reach: they take the plain form of the loads, wave-uniformly)
+                if (!OBST || __ballot(nb_next != 0u) == 0ull) F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, 0u, stage);
+                else F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage);
             }
         }
         const unsigned nb_next2 = L + 2 <= ze ? nb_of(L + 2) : 0u;
@@ -302,7 +304,10 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
             __syncthreads();
             if (second && (!OBST || __ballot(second && !(nb_cur & 1u)) != 0ull)) {
                 float f[Q], o[Q];
-                F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb_cur, below, cur, above, f);
+                if (!OBST || __ballot(nb_cur != 0u) == 0ull)
+                    F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, 0u, below, cur, above, f);
+                else
+                    F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb_cur, below, cur, above, f);
                 F2_COLLIDE(f, o);
                 // the staged loads have had the whole second step to land; waiting for them HERE keeps the
                 // latency of the stores below out of the next iteration (stores count in vmcnt too)
