@@ -659,6 +659,19 @@ static int fused_prepare(lbm_ctx* c) {
             fused_cells += (long long)std::min(64, g.W - r.bx * 64) * tyn * n;
         }
     }
+    if (c->f2_obst_blocks) {   // fused_cells counts cells the kernel UPDATES: take the solid cells inside the blocks off
+        std::vector<unsigned long long> mw((size_t)(g.D + 2) * g.H * g.Wm);
+        HIPCHK(c, hipMemcpyAsync(mw.data(), c->mask, mw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        long long solid = 0;
+#pragma omp parallel for schedule(static) reduction(+ : solid)
+        for (int z = 0; z < g.D; z++)
+            for (int y = 0; y < g.H; y++)
+                for (int xs = 0; xs < g.Wt; xs++)
+                    if (covered[tile(xs, y, z)] && fl[tile(xs, y, z)] != 0)
+                        solid += __builtin_popcountll(mw[((size_t)(z + 1) * g.H + y) * g.Wm + xs]);
+        fused_cells -= solid;
+    }
     if (getenv("LBM_FUSED_DEBUG")) {   // planning summary for tools/fused_bench.py
         long long f0 = 0, f1 = 0, f2 = 0;
         for (long long i = 0; i < ntiles; i++) { f0 += fl[(size_t)i] == 0; f1 += fl[(size_t)i] == 1; f2 += fl[(size_t)i] == 2; }

