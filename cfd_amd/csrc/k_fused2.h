@@ -40,6 +40,10 @@ struct FusedGrid {
     int zchunk;             // most layers a block takes
 };
 
+// populations whose first-step loads carry the non-temporal hint (bit k), as LBM_NT_SET for the one-step kernel
+#ifndef F2_NT_SET
+#define F2_NT_SET 0u
+#endif
 constexpr int F2_LCOLS = 66;   // 64 cells + one halo column each side
 // LDS plane of an exchanged population: 0..3 up-going oblique (11,14,15,18), 4..11 in-plane (1,2,3,4,7,8,9,10),
 // 12..15 down-going oblique (12,13,16,17); -1: own column (0, 5, 6), stays in registers
@@ -130,7 +134,7 @@ struct F2 {
                                                  bool xl, bool xr, unsigned nb, float* stage) {
         F2<PRESET, K - 1>::issue(base, g, off, offm, xl, xr, nb, stage);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)),
-                                         (__attribute__((address_space(3))) void*)(stage + K * 64), 4, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage + K * 64), 4, 0, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
     }
     // the same loads straight into registers (no prefetch)
     static __device__ __forceinline__ void load(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
