@@ -30,7 +30,8 @@ def test_headless_driver_known_answer(tmp_path):
     assert os.path.getsize(prefix + ".solid.raw") == 64 ** 3
 
 
-@pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--scheme", "slide"], ["--preset", "cavity"], ["--autotune", "--steps", "120"]])
+@pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--scheme", "slide"], ["--preset", "cavity"], ["--autotune", "--steps", "120"],
+                                   ["--single-steps"]])
 def test_native_rccl_slab_driver(extra):
     """tools/lbm_slab_rccl.cpp: C++ host, RCCL ncclSend/ncclRecv between the slabs of one process.
     On this one-GPU box the wind-tunnel ring sends to itself through RCCL; --check compares with the
@@ -41,3 +42,9 @@ def test_native_rccl_slab_driver(extra):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-identical" in r.stdout, r.stdout
+    # A/B slabs run all but the last step of a batch as pairs of steps (lbm_pair_*), everything else single steps
+    pairs = int(r.stdout.split(" pairs of steps")[0].rsplit("(", 1)[1])
+    if "--single-steps" in extra or "--scheme" in extra:
+        assert pairs == 0
+    elif not extra:
+        assert pairs == 7, r.stdout          # 25 steps = 10 warm-up + 15 timed = 7 pairs + 1 single step

@@ -4,12 +4,18 @@
 // the C++ twin of cfd_amd/slab.py, which drives the same ABI from one process per GPU.
 //
 //   lbm_slab_rccl [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity]
-//                 [--scheme ab|aa|slide] [--autotune] [--check]
+//                 [--scheme ab|aa|slide] [--autotune] [--single-steps] [--check]
 //
 // Per step and slab (two streams):
 //   side stream : lbm_step_boundary_layers (writes both outgoing messages) -> ncclSend/ncclRecv
 //   main stream : lbm_step_interior_layers, meanwhile
 //   main stream : waits for the exchange, lbm_halo_unpack_both, lbm_step_finish
+// Where every slab offers it (A/B, two steps per pass: lbm_pair_available) all but the last step run as PAIRS:
+//   side stream : lbm_pair_boundary_first -> exchange -> lbm_halo_unpack_both -> lbm_pair_boundary_second
+//                 -> exchange -> lbm_halo_unpack_both
+//   main stream : lbm_pair_interior (the fused kernel advances the interior by two steps meanwhile)
+//   main stream : waits for the side stream, lbm_pair_finish
+// (--single-steps keeps every step a single split step.)
 // The wind-tunnel preset exchanges around a ring (the reference's unchecked outlet index wraps from
 // the last z layer to the first, quirk Q2), the cavity along an open chain.
 // --check runs the undecomposed domain on GPU 0 as well and compares density and velocity bit for bit.
@@ -66,7 +72,7 @@ static void exchange(std::vector<Slab>& slabs, size_t nfloats, bool on_side) {
 
 int main(int argc, char** argv) {
     int W = 256, H = 256, D = 256, P = 0, steps = 100, preset = LBM_PRESET_WIND_TUNNEL_REF, scheme = LBM_SCHEME_AB;
-    bool check = false, autotune = false;
+    bool check = false, autotune = false, single_steps = false;
     std::string obj;
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* a) { return !std::strcmp(argv[i], a); };
@@ -78,7 +84,8 @@ int main(int argc, char** argv) {
         else if (is("--scheme") && i + 1 < argc) { ++i; scheme = !std::strcmp(argv[i], "aa") ? LBM_SCHEME_AA : (!std::strcmp(argv[i], "slide") ? LBM_SCHEME_SLIDE : LBM_SCHEME_AB); }
         else if (is("--check")) check = true;
         else if (is("--autotune")) autotune = true;
-        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--autotune] [--check]\n", argv[0]); return 2; }
+        else if (is("--single-steps")) single_steps = true;
+        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--autotune] [--single-steps] [--check]\n", argv[0]); return 2; }
     }
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
@@ -166,6 +173,47 @@ int main(int argc, char** argv) {
             }
         }
     };
+    // two steps per exchange pattern (cfd_amd/slab.py SlabSolver._step is the same schedule from Python)
+    auto pair_all = [&](int npairs) {
+        for (int it = 0; it < npairs; it++) {
+            for (Slab& s : slabs) {
+                HIP_OK(hipSetDevice(s.dev));
+                HIP_OK(hipStreamWaitEvent(s.side, s.main_done, 0));
+                LBM_OKAY(s.ctx, lbm_pair_boundary_first(s.ctx, s.down >= 0 ? s.send[0] : nullptr, s.up >= 0 ? s.send[1] : nullptr));
+            }
+            for (Slab& s : slabs) LBM_OKAY(s.ctx, lbm_pair_interior(s.ctx));
+            exchange(slabs, nfloats, true);
+            for (Slab& s : slabs) {   // the neighbours' t+1 layers, then the boundary layers' second step: side stream
+                LBM_OKAY(s.ctx, lbm_halo_unpack_both(s.ctx, s.down >= 0 ? s.recv[0] : nullptr, s.up >= 0 ? s.recv[1] : nullptr));
+                LBM_OKAY(s.ctx, lbm_pair_boundary_second(s.ctx, s.down >= 0 ? s.send[0] : nullptr, s.up >= 0 ? s.send[1] : nullptr));
+            }
+            exchange(slabs, nfloats, true);
+            for (Slab& s : slabs) {
+                HIP_OK(hipSetDevice(s.dev));
+                LBM_OKAY(s.ctx, lbm_halo_unpack_both(s.ctx, s.down >= 0 ? s.recv[0] : nullptr, s.up >= 0 ? s.recv[1] : nullptr));
+                HIP_OK(hipEventRecord(s.side_done, s.side));
+                HIP_OK(hipStreamWaitEvent(s.main, s.side_done, 0));
+                LBM_OKAY(s.ctx, lbm_pair_finish(s.ctx));
+                HIP_OK(hipEventRecord(s.main_done, s.main));
+            }
+        }
+    };
+    auto pairs_offered = [&] {
+        if (single_steps) return false;
+        for (Slab& s : slabs) {
+            int a = 0;
+            LBM_OKAY(s.ctx, lbm_pair_available(s.ctx, &a));
+            if (!a) return false;
+        }
+        return true;
+    };
+    // n steps: pairs for all but the last one or two (the last step of a batch stays a single step: rho/u on demand)
+    auto advance = [&](int n) {
+        const int pairs = (n >= 3 && pairs_offered()) ? (n - 1) / 2 : 0;
+        pair_all(pairs);
+        step_all(n - 2 * pairs);
+        return pairs;
+    };
     auto sync_all = [&] {
         for (Slab& s : slabs) { HIP_OK(hipSetDevice(s.dev)); HIP_OK(hipDeviceSynchronize()); }
     };
@@ -211,16 +259,16 @@ int main(int argc, char** argv) {
     const int warm = steps - tuned > 20 ? 10 : 0;
     steps -= tuned;  // the trials were ordinary steps of the simulation
     if (steps < warm) steps = warm;
-    step_all(warm);
+    advance(warm);
     sync_all();
     const auto t0 = std::chrono::steady_clock::now();
-    step_all(steps - warm);
+    const int paired = advance(steps - warm);
     sync_all();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double cells = (double)W * H * D;
-    std::printf("%dx%dx%d in %d z-slabs over RCCL (%s, %s): %d steps, %.3f ms/step, %.1f MLUPS\n", W, H, D, P,
+    std::printf("%dx%dx%d in %d z-slabs over RCCL (%s, %s): %d steps (%d pairs of steps in the timed part), %.3f ms/step, %.1f MLUPS\n", W, H, D, P,
                 ring ? "wind tunnel, ring" : "cavity, chain", scheme == LBM_SCHEME_AA ? "AA" : (scheme == LBM_SCHEME_SLIDE ? "sliding A/B" : "A/B"), steps + tuned,
-                dt / (steps - warm) * 1e3, cells * (steps - warm) / dt / 1e6);
+                paired, dt / (steps - warm) * 1e3, cells * (steps - warm) / dt / 1e6);
 
     int bad = 0;
     if (check) {
