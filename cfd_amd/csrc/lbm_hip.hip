@@ -566,7 +566,6 @@ static int fused_prepare(lbm_ctx* c) {
     std::vector<std::vector<Run>> runs_of((size_t)fg.nby);
     std::vector<unsigned char> touches((size_t)fg.nby, 0);
     const bool obst = c->f2_obst;
-    const int wanted_pct = getenv("LBM_FUSED_WANTED") ? atoi(getenv("LBM_FUSED_WANTED")) : 34;   // experiment knob
 #pragma omp parallel for schedule(dynamic, 1)
     for (int by = 0; by < fg.nby; by++) {
         const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
@@ -587,7 +586,7 @@ static int fused_prepare(lbm_ctx* c) {
                 if (!obst || outlet_tile) return true;
                 int fluid = 0;
                 for (int y = y0; y < y0 + tyn; y++) fluid += fl[tile(bx, y, z)] != 2;
-                return fluid * 100 >= tyn * wanted_pct;
+                return fluid * 3 >= tyn;   // (thresholds from 1 % to 100 % of the rows move configs[2] by under 1 %)
             };
             int z = 0;
             while (z < g.D) {
