@@ -112,8 +112,14 @@ def dry_run_rank(args):
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the timed step count as the GPU path settles it: every rank's own clock suggests another number
+    calls = []
+    n, _, _, _ = timed_steps(type("S", (), {"timer_begin": lambda s: None, "timer_end": lambda s: 0.0, "stats": lambda s: {}})(),
+                             calls.append, 20, 1e-4 * (rank + 1), lambda: None, probe_steps=3,
+                             agree=(lambda k: agree_steps(dist, k)) if world > 1 else None)
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "gpus_arg": args.gpus}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "gpus_arg": args.gpus,
+                          "agreed_steps": n, "stepped": calls[-1]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -210,9 +216,19 @@ def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kern
     return out
 
 
-def timed_steps(solver, step, steps_requested, min_seconds, fence, probe_steps=10):
+def agree_steps(dist, n, device=None):
+    """every rank must run the SAME number of steps (each step is an exchange with the neighbours): the largest
+    any rank asks for"""
+    import torch
+    t = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t[0])
+
+
+def timed_steps(solver, step, steps_requested, min_seconds, fence, probe_steps=10, agree=None):
     """warm-up is done by the caller.  Times ONE step(n) call with n >= steps_requested chosen so that the region
-    lasts at least min_seconds; returns (n, wall seconds, device ms, stats)."""
+    lasts at least min_seconds; returns (n, wall seconds, device ms, stats).  `agree`: ranks that step together
+    settle on one n (their clocks differ)."""
     n = steps_requested
     if min_seconds > 0:
         fence()
@@ -221,6 +237,8 @@ def timed_steps(solver, step, steps_requested, min_seconds, fence, probe_steps=1
         fence()
         per = (time.perf_counter() - t0) / probe_steps
         n = max(steps_requested, int(min_seconds / max(per, 1e-7)) + 1)
+    if agree is not None:
+        n = agree(n)
     fence()
     solver.timer_begin()
     t0 = time.perf_counter()
@@ -332,7 +350,8 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
             torch.cuda.synchronize()
 
         drv.step(warmup)
-        n, dt, dev_ms, st = timed_steps(solver, drv.step, steps, min_seconds, fence)
+        n, dt, dev_ms, st = timed_steps(solver, drv.step, steps, min_seconds, fence,
+                                        agree=lambda k: agree_steps(dist, k, "cuda"))
         tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, dev_ms = float(tmax[0]), float(tmax[1])

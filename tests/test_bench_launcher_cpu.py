@@ -23,6 +23,9 @@ def test_gpus_2_self_launches_two_ranks():
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) == 1, out                       # stdout carries exactly the one JSON line
     rec = json.loads(lines[0])
+    # every rank's own clock suggests another timed step count; they must all run the one they agreed on
+    agreed = rec.pop("agreed_steps")
+    assert rec.pop("stepped") == agreed >= 20
     assert rec == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "gpus_arg": 2}
     assert "torch.distributed.run" in err and "--nproc-per-node=2" in err
 
@@ -39,4 +42,6 @@ def test_under_torchrun_it_is_one_rank():
 def test_gpus_1_plain_does_not_launch():
     rc, out, err = run_bench("--gpus", "1", "--dry-run-launcher")
     assert rc == 0, err[-2000:]
-    assert json.loads(out.strip()) == {"dry_run": True, "n_gpus": 1, "max_over_ranks": 1.0, "gpus_arg": 1}
+    rec = json.loads(out.strip())
+    assert rec.pop("stepped") == rec.pop("agreed_steps")
+    assert rec == {"dry_run": True, "n_gpus": 1, "max_over_ranks": 1.0, "gpus_arg": 1}
