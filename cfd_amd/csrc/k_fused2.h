@@ -18,12 +18,14 @@
 // The next layer's 19 loads travel global -> LDS (global_load_lds_dword, no registers held in flight)
 // while all this happens.
 //
-// Scope: tiles whose haloed neighbourhood is plain fluid (tile flag 0 everywhere: no wall row, no solid cell
-// in reach), with the x ends of the domain handled in place exactly as k_stream_collide's interior path
-// does (inlet constant / outlet copy of the reference chain, lbm_solver.cu:283-296, or the cavity's wall
-// bounce-back).  Every other cell -- the rim -- takes two ordinary steps through a third buffer (host side:
-// fused_pair() in lbm_hip.hip).  The arithmetic per cell is moments_of() + collide_cell() on the same
-// operands in the same order as two single steps, so results are bit-identical (tests/test_fused_gpu.py).
+// Scope: blocks of tiles whose haloed neighbourhood keeps off the domain's walls (no wall row, no wall layer),
+// with the x ends of the domain handled in place exactly as k_stream_collide's interior path does (inlet
+// constant / outlet copy of the reference chain, lbm_solver.cu:283-296, or the cavity's wall bounce-back), and
+// -- in the OBST form of the kernel -- with solid cells inside: a direction that would pull from a solid cell
+// takes the own cell's opposite population (lbm_solver.cu:298-318).  Every other cell -- the rim -- takes two
+// ordinary steps through a third buffer (host side: fused_pair() in lbm_hip.hip).  The arithmetic per cell
+// is collide_packed() (d3q19.h): moments_of() + collide_cell() on the same operands in the same order, so
+// results are bit-identical to two single steps (tests/test_fused_gpu.py).
 
 // LBM_F2_SCALAR_COLLIDE: the scalar moments_of() + collide_cell() instead of collide_packed() (same bits)
 #ifdef LBM_F2_SCALAR_COLLIDE
