@@ -165,6 +165,8 @@ def test_fused_blocks_hold_obstacles(oracle, lbm, monkeypatch):
                     s.add_solid(150 + i, 20 + i, 15 + i, 1, 1, 1)
                 s.add_solid(63, 25, 20, 1, 1, 1)            # single cell at a tile's last column / next tile's first
                 s.add_solid(64, 27, 22, 1, 1, 1)
+                s.add_solid(0, 30, 10, 3, 6, 5)             # in the inlet column / on the cavity's x = 0 wall
+                s.add_solid(W - 2, 14, 25, 2, 5, 4)         # in the outlet column / on the x = W-1 wall
             o.step(11); g.step(11)
             same(o, g, f"LBM_FUSED_OBST={obst}, preset {preset}")
             if fused_in_use(lbm, g, may_decline=obst == "0"):
