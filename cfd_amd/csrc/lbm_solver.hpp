@@ -8,8 +8,10 @@
 //   ---------------------------------------     ------------------------------------------------
 //   struct settings (lbm_solver.cuh:9-15)        same fields and defaults; read at every step()
 //   cuda_math::vec4 (cuda_math.cuh:37-55)        same 16-byte {x,y,z,w}
-//   cuda_buffer<T> (cuda_buffer.cuh:18-122)      hip_buffer<T>: copy_to_host / get_data views of
-//                                                the solver's fields in the reference wire format
+//   cuda_buffer<T> (cuda_buffer.cuh:18-122)      hip_buffer<T>: the same members (release, memset, copy_from_host,
+//                                                copy_to_host, copy_from_device, copy_to_device, get_data,
+//                                                set_size) as views of the solver's fields in the reference
+//                                                wire format
 //   CUDA_CHECK -> log + exit (cuda_buffer.cuh:9) LBM_CHECK -> log + std::exit(EXIT_FAILURE)
 //   register_external_* (lbm_solver.cu:558-717)  throw std::runtime_error (CUDA-Vulkan interop is
 //                                                out of scope)
