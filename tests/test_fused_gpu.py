@@ -192,3 +192,29 @@ def test_fused_equals_single_steps_car_512(lbm):
     np.testing.assert_array_equal(a.density(), b.density())
     np.testing.assert_array_equal(a.velocity(), b.velocity())
     assert np.array_equal(a.populations(), b.populations())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fused_random_masks_equal_single_steps(lbm, seed):
+    """random masks (scattered single cells at three densities plus random boxes: every tile has solids in
+    reach) on both presets: the two-steps-per-pass path against the one-step kernel, which the oracle tests pin"""
+    rng = np.random.default_rng(seed)
+    W, H, D = 192 + 8 * seed, 40 + seed, 30 + 2 * seed
+    m = (rng.random((D, H, W)) < (0.002, 0.02, 0.1, 0.3)[seed - 1]).astype(np.uint8) * 255
+    for _ in range(6):
+        x, y, z = rng.integers(0, W - 8), rng.integers(0, H - 6), rng.integers(0, D - 6)
+        m[z:z + rng.integers(1, 6), y:y + rng.integers(1, 6), x:x + rng.integers(1, 40)] = 255
+    for preset in (0, 1):
+        a = lbm.Solver(W, H, D, preset, two_step=lbm.TWO_STEP_OFF)
+        b = lbm.Solver(W, H, D, preset)
+        for s in (a, b):
+            s.init(); s.set_solid(m)
+            if preset == 1:
+                s.set_params(0.05, 1.6, 1.7)
+        for n in (9, 4):
+            a.step(n); b.step(n)
+            np.testing.assert_array_equal(a.density(), b.density())
+            np.testing.assert_array_equal(a.velocity(), b.velocity())
+            assert np.array_equal(a.populations(), b.populations())
+        assert a.stats()["fused_cells"] == 0
+        fused_in_use(lbm, b, may_decline=True)
