@@ -217,4 +217,4 @@ def test_fused_random_masks_equal_single_steps(lbm, seed):
             np.testing.assert_array_equal(a.velocity(), b.velocity())
             assert np.array_equal(a.populations(), b.populations())
         assert a.stats()["fused_cells"] == 0
-        fused_in_use(lbm, b, may_decline=True)
+        fused_in_use(lbm, b, may_decline=seed == 4)
