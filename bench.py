@@ -12,8 +12,12 @@ read + written; rho/u are not written per step).  The timed region is ONE lbm_st
 library advances two steps per pass where it can (k_fused2, lbm_opts.two_step).  `steps` in the line is what
 was timed: the requested K, raised until the timed region lasts at least --min-seconds (0.5 s).
 
-Headline (--config 1): BASELINE.json configs[1], the 256^3 lid-driven cavity, populations resident in HBM.
-N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) cavity and exchanges the five
+Headline (--config 1): the size of BASELINE.json configs[1], 256^3 fp32 with no interior solids, on the REFERENCE's
+boundary chain and default parameters (wind tunnel: lbm_solver.cu:283-318, lbm_solver.cuh:9-15) -- the kernel that
+is parity-checked against the reference's arithmetic is the one that is timed.  The
+lid-driven cavity configs[1] names is not a reference boundary set (our own preset); it runs in the `configs` array
+(and as the headline with `--preset cavity`).  Populations resident in HBM.
+N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) tunnel and exchanges the five
 face-crossing populations per face per step with its neighbours by RCCL send/recv (torch.distributed backend
 "nccl"), overlapped with the interior update.
 --config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised car stand-in
@@ -31,7 +35,9 @@ Beside the headline the one JSON line carries
                     boundary chain, and the reference-equivalent output modes (rho/u written every step: 172 B per
                     cell; + curl every step: 192 B per cell; lbm_solver.cu:336-337,488);
   * `strong_scaling` configs[3] split over the N ranks through the z-slab code path (at N = 1: one slab, RCCL
-                    ring to itself): MLUPS, ms per step, halo bytes per step, exposed communication time.
+                    ring to itself): MLUPS, ms per step, halo bytes per step, exposed communication time; at N = 1
+                    also `rehearsal_8`: each of the eight 64-layer slabs an 8-GPU run would hold, stepped on this
+                    one GPU (RCCL ring to itself), and `projected_efficiency_8` = T1 / (8 x the slowest slab).
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 import argparse
@@ -56,7 +62,7 @@ CAVITY_PARAMS = dict(inlet_velocity=0.08, omega_shear=1.8, omega_bulk=1.9)
 CAR = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
 # per-config workload: (per-GPU size, preset, scheme, obstacle, scaling)
-CONFIGS = {1: ((256, 256, 256), "cavity", "ab", None, "weak"),
+CONFIGS = {1: ((256, 256, 256), "wind_tunnel", "ab", None, "weak"),
            2: ((512, 256, 256), "wind_tunnel", "ab", "car", "weak"),
            3: ((1024, 512, 512), "wind_tunnel", "ab", "car", "strong"),
            # configs[4] names the AA pattern; the headline runs the faster of the two in-place schemes (sliding A/B:
@@ -81,16 +87,39 @@ def free_port():
     return port
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, timeout_s=None):
     """Start n ranks of this script under torch.distributed.run and relay rank 0's JSON line.  Runs before
-    this process has imported torch or touched the GPU (a process that has must never exec another)."""
+    this process has imported torch or touched the GPU (a process that has must never exec another).  The ranks
+    run in a process group of their own; when they have not finished after `timeout_s` (BENCH_LAUNCH_TIMEOUT,
+    default 900 s) -- one dead rank leaves the others waiting in a collective -- the whole group is killed and the
+    launcher exits non-zero instead of hanging until somebody else's limit."""
+    import signal
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "900"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     log("[bench] starting", n, "ranks:", " ".join(cmd))
     env = dict(os.environ)
+    # this pool's host driver supports dmabuf IPC only: without it RCCL's cross-process buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument` (stated for this image and its GPU boxes, where the variable is
+    # already exported; set here for shells that lost it)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] the ranks did not finish within {timeout_s:.0f} s: killing their process group")
+        for sig in (signal.SIGTERM, signal.SIGKILL):   # the group, not just its leader: the ranks are grandchildren
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        return 124
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
     if lines:
         sys.stdout.write(lines[-1] + "\n")
         sys.stdout.flush()
@@ -117,6 +146,8 @@ def dry_run_rank(args):
     n, _, _, _ = timed_steps(type("S", (), {"timer_begin": lambda s: None, "timer_end": lambda s: 0.0, "stats": lambda s: {}})(),
                              calls.append, 20, 1e-4 * (rank + 1), lambda: None, probe_steps=3,
                              agree=(lambda k: agree_steps(dist, k)) if world > 1 else None)
+    if os.environ.get("BENCH_DRY_RUN_HANG") == str(rank):     # test of the launcher's time limit: this rank never returns
+        time.sleep(3600)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "gpus_arg": args.gpus,
                           "agreed_steps": n, "stepped": calls[-1]}), flush=True)
@@ -182,35 +213,95 @@ def cpu_baseline(W, H, D, preset, obj=None, budget_s=12.0):
 # ------------------------------------------------------------------------------------------------
 # measurement helpers
 # ------------------------------------------------------------------------------------------------
+def source_hashes():
+    """git blob hashes of the sources the hot kernels are built from (what `git hash-object` prints): a counter
+    profile under profiles/ is quoted only for the tree it was taken on."""
+    import hashlib
+    out = {}
+    for name in ("k_fused2.h", "k_step.h", "k_aa.h", "d3q19.h"):
+        with open(os.path.join(ROOT, "cfd_amd", "csrc", name), "rb") as f:
+            data = f.read()
+        out[name] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
+def counter_traffic(kernel, cell_updates_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_*_traffic.json, written
+    by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; counters cannot be read from
+    inside this process).  None unless a profile of the same kernel on the same workload (equal cell updates per
+    launch) exists AND was taken on this very source (equal blob hashes)."""
+    import glob
+    mine = source_hashes()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_traffic.json"))):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") != kernel or int(t.get("cell_updates_per_launch", -1)) != int(cell_updates_per_launch):
+            continue
+        if any(mine.get(k) != v for k, v in t.get("source_hashes", {}).items()) or not t.get("source_hashes"):
+            continue
+        return t, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kernel=None):
-    """The dominant kernel of the timed region against the HBM roofline.  `achieved` = algorithmic bytes per
-    launch (bytes_per_cell x the cell updates one launch performs) / the launch's device time."""
+    """The dominant kernel of the timed region against the HBM roofline, per LAUNCH (device time from HIP events on
+    the solver's stream).
+
+    One step per pass (k_stream_collide, k_aa_step): a launch reads and writes the 19 populations of every cell it
+    updates once: 152 B per cell update are its algorithmic bytes; `frac` = those / time / peak.
+
+    Two steps per pass (k_fused2): a launch advances its cells by TWO updates but reads and writes their populations
+    ONCE, so ITS algorithmic bytes are 152 B per cell and launch = 76 B per cell update (`floor_bytes_per_launch`;
+    the tile halo comes on top in practice).  Three fractions, none of which needs recomputing:
+      frac / frac_of_floor   floor bytes / time / peak: how close the launch is to the least it must move;
+      hbm_frac               what the launch really moves through HBM by the PMC counters (profiles/, with the
+                             kernel symbol and the source hashes it was taken on; null when the tree differs);
+      effective_frac         every update priced at SURVEY 8d's 152 B: what a one-step kernel would need to
+                             sustain for the same updates per second.  Can exceed 1: that is the point of the scheme."""
     fl, fms = stats["last_timed_fused_launches"], stats["last_timed_fused_ms"]
-    if fl and fms > 0:
-        # two steps per pass: one k_fused2 launch advances fused_cells cells by two steps (all of them fluid);
-        # its own device time comes from HIP events around every launch
+    two_step = bool(fl and fms > 0)
+    if two_step:
         launch_ms = fms / fl
         updates = 2 * stats["fused_cells"]
         name, launches_per_step = "k_fused2", fl / steps
+        algorithmic = stats["fused_cells"] * bytes_per_cell       # one read + one write of every cell of the blocks
     else:
         launches = max(1, stats["last_timed_launches"])
         launch_ms = dev_ms / launches
         updates = fluid * steps / launches
         name, launches_per_step = kernel or "k_stream_collide", launches / steps
-    by = updates * bytes_per_cell
-    achieved = by / (launch_ms * 1e-3) / 1e9
+        algorithmic = updates * bytes_per_cell
+    sec = launch_ms * 1e-3
+    achieved = algorithmic / sec / 1e9
     out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": name,
            "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches_per_step, 3),
-           "algorithmic_bytes_per_launch": round(by), "cell_updates_per_launch": round(updates),
-           "bytes_per_cell_update": bytes_per_cell}
-    if fl and fms > 0:
-        # the launch really moves about half of that (one read + one write per TWO updates, plus the tile halo);
-        # the counter figure is in profiles/ (rocprofv3 --pmc passes cannot run inside this process)
-        out["note"] = ("two cell updates per pass: `achieved` prices every update at the 152 algorithmic bytes SURVEY.md 8d "
-                       "defines, so it can exceed the HBM peak; what the launch really moves through HBM is in "
-                       "profiles/r02_*_pmc_traffic.txt (counters cannot be read from inside this process)")
-        out["whole_step_frac"] = round(fluid * steps * bytes_per_cell / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+           "algorithmic_bytes_per_launch": round(algorithmic), "cell_updates_per_launch": round(updates),
+           "bytes_per_cell_update": bytes_per_cell // 2 if two_step else bytes_per_cell}
+    prof, path = counter_traffic(name, round(updates))
+    if prof:
+        traffic = prof["fetch_bytes"] + prof["write_bytes"]
+        out["traffic"] = round(traffic)
+        out["hbm_frac"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
+        out["traffic_over_algorithmic"] = round(traffic / algorithmic, 4)
+        out["traffic_source"] = {"file": path, "kernel_symbol": prof.get("kernel_symbol"), "dispatches": prof.get("dispatches"),
+                                 "profiled_launch_us": prof.get("launch_us"), "source_hashes": prof.get("source_hashes")}
+    else:
+        out["hbm_frac"] = None
+    if two_step:
+        out["floor_bytes_per_launch"] = round(algorithmic)
+        out["frac_of_floor"] = out["frac"]
+        eff = updates * bytes_per_cell / sec / 1e9
+        out["effective_achieved"] = round(eff, 1)
+        out["effective_frac"] = round(eff / HBM_PEAK_GBS, 4)
+        out["note"] = ("two cell updates per pass over HBM: `frac` = `frac_of_floor` prices the launch at what it must move "
+                       "(one read + one write of its cells, 152 B per cell and launch); `effective_frac` prices every update "
+                       "at SURVEY.md 8d's 152 B and can exceed 1; `hbm_frac` is the PMC-counter traffic from profiles/ "
+                       "(null when no profile of this kernel on this workload was taken on this source tree)")
+        out["whole_step_effective_frac"] = round(fluid * steps * bytes_per_cell / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["fused_share_of_cells"] = round(stats["fused_cells"] / max(1, stats["cells"]), 4)
         out["fused_share_of_time"] = round(fms / dev_ms, 4)
     return out
@@ -317,30 +408,56 @@ def run_single(lbm, size, preset_name, scheme_name, obstacle, steps, warmup, min
         solver.close()
 
 
+def all_ranks_ok(dist, ok, what):
+    """every rank says whether it got this far; if one did not, ALL raise together (a rank that raised alone would
+    leave the others waiting in the next collective until RCCL's timeout)"""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t[0]) == 0:
+        raise RuntimeError(f"{what} failed on {'this rank' if not ok else 'another rank'}")
+
+
 def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmup, min_seconds, world, rank, local_rank, dist,
-              want_exposed=True):
+              want_exposed=True, rehearse=None, ranges=None):
     """This rank's z-slab of the domain through the split step + RCCL halo exchange (cfd_amd/slab.py).  `dist` is an
-    initialised torch.distributed (world 1: a ring to itself)."""
+    initialised torch.distributed (world 1: a ring to itself).
+    rehearse = (r, P) at world 1: slab r of the P an P-GPU run would hold (layers [r D/P, (r+1) D/P) of the global
+    domain, its share of the obstacle), with its RCCL ring closed on itself: the launches, message sizes and the
+    two-stream schedule of rank r of P, on one GPU.
+    ranges = [(z0, layers)] per part (default: an even split)."""
     import torch
     from cfd_amd import slab
     W, H, Dg = size_global
-    D = Dg // world
+    parts, part = (rehearse[1], rehearse[0]) if rehearse else (world, rank)
+    if ranges is None:
+        ranges = [slab.slab_range(Dg, parts, r) for r in range(parts)]
+    z0, D = ranges[part]
     preset = lbm.PRESET_CAVITY if preset_name == "cavity" else lbm.PRESET_WIND_TUNNEL
     scheme = {"ab": lbm.SCHEME_AB, "aa": lbm.SCHEME_AA, "slide": lbm.SCHEME_SLIDE}[scheme_name]
     # two streams: boundary layers + RCCL on a side stream beside the interior update (3-4 % faster
     # than one stream whenever a rank has a neighbour, tools/probes/rccl_self_probe.py)
-    eng = slab.HipSlabEngine(W, H, Dg, rank * D, D, preset, device=local_rank, scheme=scheme, two_streams=True)
+    eng, err = None, None
+    try:
+        eng = slab.HipSlabEngine(W, H, Dg, z0, D, preset, device=local_rank, scheme=scheme, two_streams=True)
+    except Exception as e:                         # e.g. out of memory on this rank only
+        err = e
+    all_ranks_ok(dist, err is None, f"slab set-up ({err})")
     solver = eng.solver
     try:
         if scheme != lbm.SCHEME_AB:
             # the in-place schemes write rho/u of the field window in every split step: keep it small
             solver.set_field_window(0, min(4, D))
         drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
-        solver.init()
-        if preset == lbm.PRESET_CAVITY:
-            solver.set_params(**CAVITY_PARAMS)
-        if obstacle:
-            solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
+        try:
+            solver.init()
+            if preset == lbm.PRESET_CAVITY:
+                solver.set_params(**CAVITY_PARAMS)
+            if obstacle:
+                solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
+        except Exception as e:
+            err = e
+        all_ranks_ok(dist, err is None, f"slab initialisation ({err})")
         drv.exchange_mask()
         drv.exchange_populations()
         drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
@@ -362,8 +479,8 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
         finite = torch.tensor([1 if state_is_finite(solver) else 0], dtype=torch.int64, device="cuda")
         dist.all_reduce(finite, op=dist.ReduceOp.MIN)
         res = {"cells_per_gpu": W * H * D, "fluid_cells_per_gpu": fluid, "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
-               "mlups": round(W * H * D * world * n / dt / 1e6, 1), "state_finite": bool(int(finite[0])),
-               "rccl_ranks": world, "slab_layers": D,
+               "mlups": round(W * H * (Dg if not rehearse else D) * n / dt / 1e6, 1), "state_finite": bool(int(finite[0])),
+               "rccl_ranks": world, "slab_layers": D, "slab_z0": z0, "slab_ranges": [list(x) for x in ranges],
                "halo_bytes_per_step_per_gpu": 4 * eng.message_floats() * ((drv.up is not None) + (drv.down is not None)),
                "roofline": roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")}
         res["two_steps_per_pass"] = res["roofline"]["kernel"] == "k_fused2"
@@ -381,10 +498,13 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
                 ms_plain = (time.perf_counter() - t0) / m * 1e3
             finally:
                 drv.t = real
-            tp = torch.tensor([ms_plain], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            res["ms_per_step_no_exchange"] = round(float(tp[0]), 5)
-            res["exposed_comm_ms_per_step"] = round(max(0.0, dt / n * 1e3 - float(tp[0])), 5)
+            # every rank's own figure (no waiting on neighbours in it): what the slabs are balanced by
+            own = torch.zeros(world, dtype=torch.float64, device="cuda")
+            own[rank] = ms_plain
+            dist.all_reduce(own, op=dist.ReduceOp.SUM)
+            res["per_rank_ms_no_exchange"] = [round(float(x), 5) for x in own]
+            res["ms_per_step_no_exchange"] = round(float(own.max()), 5)
+            res["exposed_comm_ms_per_step"] = round(max(0.0, dt / n * 1e3 - float(own.max())), 5)
         return res
     finally:
         solver.close()
@@ -394,10 +514,10 @@ def sweep_single_gpu(lbm, device, budget):
     """Every other single-GPU configuration / output mode for a few steps each (N = 1 only)."""
     out = []
     plan = [
-        ("256^3 wind tunnel, reference boundary chain, A/B", None, (256, 256, 256), "wind_tunnel", "ab", None, {}),
+        ("256^3 lid-driven cavity (BASELINE.json configs[1] as named; our own preset, not a reference boundary set), A/B", 1, (256, 256, 256), "cavity", "ab", None, {}),
+        ("256^3 wind tunnel, one step per pass (two_step off)", 1, (256, 256, 256), "wind_tunnel", "ab", None, {"two_step": False}),
         ("256^3 wind tunnel, rho/u written every step (reference-equivalent output, 172 B/cell)", None, (256, 256, 256), "wind_tunnel", "ab", None, {"mode": "rho_u"}),
         ("256^3 wind tunnel, rho/u + curl every step (reference-equivalent output, 192 B/cell)", None, (256, 256, 256), "wind_tunnel", "ab", None, {"mode": "rho_u_curl"}),
-        ("256^3 cavity, one step per pass (two_step off)", 1, (256, 256, 256), "cavity", "ab", None, {"two_step": False}),
         ("512x256x256 wind tunnel + car, A/B", 2, (512, 256, 256), "wind_tunnel", "ab", "car", {}),
         ("512x256x256 wind tunnel + car, sliding in-place", 2, (512, 256, 256), "wind_tunnel", "slide", "car", {"field_window": (0, 4)}),
         ("1024x512x512 wind tunnel + car, one GPU, A/B", 3, (1024, 512, 512), "wind_tunnel", "ab", "car", {"field_window": (0, 4)}),
@@ -437,6 +557,11 @@ def main():
     ap.add_argument("--one-step", action="store_true", help="turn the two-steps-per-pass path off (lbm_opts.two_step)")
     ap.add_argument("--rehearse-slab", action="store_true",
                     help="N = 1 only: run the headline through the z-slab code path of N > 1 (split step, RCCL ring to itself)")
+    ap.add_argument("--slab-index", type=int, default=None,
+                    help="with --rehearse-slab: rehearse slab R of --slabs (default 8) of the configuration's global domain")
+    ap.add_argument("--slabs", type=int, default=8)
+    ap.add_argument("--no-balance", action="store_true", help="strong scaling: keep the even split of the depth (no cost-balanced slabs)")
+    ap.add_argument("--no-rehearsal-8", action="store_true", help="N = 1: skip the eight 64-layer slab rehearsals of `strong_scaling`")
     ap.add_argument("--dry-run-launcher", action="store_true", help="CPU test of the N > 1 launcher: gloo rendezvous only")
     args = ap.parse_args()
 
@@ -469,8 +594,8 @@ def main():
     scheme_name = args.scheme or scheme_name
     W, H, D = size
     if scaling == "strong":
-        if D % world:
-            raise SystemExit(f"--config {args.config}: depth {D} is not divisible by {world} ranks")
+        if D < 8 * world:
+            raise SystemExit(f"--config {args.config}: depth {D} is too thin for {world} ranks")
         Dg, D = D, D // world
     else:
         Dg = D * world
@@ -488,10 +613,26 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     slab_path = world > 1 or args.rehearse_slab
+    rehearse = None
+    if args.rehearse_slab and args.slab_index is not None:
+        if world != 1 or not 0 <= args.slab_index < args.slabs or Dg % args.slabs:
+            raise SystemExit("--slab-index needs N = 1, 0 <= R < --slabs and a depth divisible by --slabs")
+        rehearse = (args.slab_index, args.slabs)
     if slab_path:
         head = run_slabs(lbm, (W, H, Dg), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
-                         world, rank, local_rank, dist, want_exposed=True)
+                         world, rank, local_rank, dist, want_exposed=True, rehearse=rehearse)
+        if scaling == "strong" and world > 1 and not args.no_balance and not rehearse:
+            # re-cut the slabs for equal measured cost and run again on that partition (cfd_amd/slab.py balanced_ranges)
+            from cfd_amd import slab
+            even = [tuple(x) for x in head["slab_ranges"]]
+            cut = slab.balanced_ranges(Dg, even, head["per_rank_ms_no_exchange"])
+            if cut != even:
+                first = {k: head[k] for k in ("ms_per_step", "mlups", "slab_ranges", "per_rank_ms_no_exchange", "exposed_comm_ms_per_step")}
+                head = run_slabs(lbm, (W, H, Dg), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
+                                 world, rank, local_rank, dist, want_exposed=True, ranges=cut)
+                head["even_split"] = first
         cells, fluid = head["cells_per_gpu"], head["fluid_cells_per_gpu"]
+        D = head["slab_layers"]
     else:
         head = run_single(lbm, (W, H, D), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
                           device=local_rank, slide_chunk=args.slide_chunk,
@@ -508,8 +649,9 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, {SCHEME_TEXT[scheme_name]}, "
                                    f"{'voxelised car stand-in, ' if obstacle else ''}"
-                                   f"{'z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo' if slab_path else 'one GPU'}"
-                                   f" (BASELINE.json configs[{args.config}])",
+                                   f"{('slab ' + str(rehearse[0]) + ' of ' + str(rehearse[1]) + ' rehearsed on one GPU, ' + str(D) + ' layers, RCCL ring to itself') if rehearse else ('z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo') if slab_path else 'one GPU'}"
+                                   f" (BASELINE.json configs[{args.config}]"
+                                   f"{': its size on the reference boundary chain and defaults; the cavity as named is in `configs`' if args.config == 1 and preset_name == 'wind_tunnel' else ''})",
                        "per_gpu_cells": cells, "per_gpu_fluid_cells": fluid, "bytes_per_cell": BYTES_PER_CELL,
                        "layout": "row-interleaved [z][y][k][x], rows padded to 128 B",
                        "params": CAVITY_PARAMS if preset == lbm.PRESET_CAVITY else "reference defaults (U 0.08, omega 1.98 / 1.90)",
@@ -519,19 +661,66 @@ def main():
             "roofline": head["roofline"],
         }
         if slab_path:
-            out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "slab_layers", "halo_bytes_per_step_per_gpu",
+            out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "slab_layers", "slab_z0", "slab_ranges", "even_split", "per_rank_ms_no_exchange", "halo_bytes_per_step_per_gpu",
                                                      "ms_per_step_no_exchange", "exposed_comm_ms_per_step") if k in head}
 
-    # configs[3] over the N ranks (strong scaling), through the same slab path at every N
+    # configs[3] over the N ranks (strong scaling), through the same slab path at every N.  The tunnel around the car
+    # is not uniform in z, so after a first run on an even split the slabs are re-cut for equal measured cost
+    # (cfd_amd/slab.py balanced_ranges) and the run is repeated on that partition; both are reported.
     if not args.no_strong_scaling and not (args.config == 3 and slab_path):
+        from cfd_amd import slab
         Ws, Hs, Ds = CONFIGS[3][0]
-        if Ds % world == 0:
+        if Ds >= 8 * world:
+            sz = (Ws, Hs, Ds)
+            kw = dict(steps=20, warmup=5, world=world, rank=rank, local_rank=local_rank, dist=dist)
+            ss = None
             try:
-                ss = run_slabs(lbm, (Ws, Hs, Ds), "wind_tunnel", "ab", "car", steps=20, warmup=5, min_seconds=args.min_seconds,
-                               world=world, rank=rank, local_rank=local_rank, dist=dist, want_exposed=True)
-                ss["workload"] = f"wind_tunnel {Ws}x{Hs}x{Ds} + voxelised car stand-in, A/B, z-slabs {world} x {Ds // world} layers (BASELINE.json configs[3])"
-            except Exception as e:
+                ss = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=args.min_seconds, want_exposed=True, **kw)
+                if world > 1 and not args.no_balance:
+                    even = [tuple(x) for x in ss["slab_ranges"]]
+                    cut = slab.balanced_ranges(Ds, even, ss["per_rank_ms_no_exchange"])
+                    if cut != even:
+                        first = {k: ss[k] for k in ("ms_per_step", "mlups", "slab_ranges", "per_rank_ms_no_exchange", "exposed_comm_ms_per_step")}
+                        ss = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=args.min_seconds, want_exposed=True, ranges=cut, **kw)
+                        ss["even_split"] = first
+                ss["workload"] = (f"wind_tunnel {Ws}x{Hs}x{Ds} + voxelised car stand-in, A/B, {world} z-slabs of "
+                                  f"{[d for _, d in ss['slab_ranges']]} layers (BASELINE.json configs[3])")
+            except RuntimeError as e:              # set-up failed somewhere: every rank raised together (all_ranks_ok)
                 ss = {"error": f"{type(e).__name__}: {e}"}
+            # what an 8-GPU run would hold per GPU, one slab after the other on this GPU: the projection of the
+            # strong-scaling efficiency that a one-GPU box can measure (the slowest slab sets the step of all eight)
+            if world == 1 and "error" not in ss and not args.no_rehearsal_8 and Ds % 8 == 0:
+                def rehearse_all(ranges):
+                    rows = []
+                    for r in range(8):
+                        try:
+                            one = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=min(args.min_seconds, 0.3),
+                                            want_exposed=False, rehearse=(r, 8), ranges=ranges, **kw)
+                            rows.append({"slab": r, "z0": one["slab_z0"], "layers": one["slab_layers"], "ms_per_step": one["ms_per_step"],
+                                         "mlups": one["mlups"], "fluid_cells": one["fluid_cells_per_gpu"],
+                                         "k_fused2_launch_ms": one["roofline"].get("launch_ms"),
+                                         "fused_share_of_cells": one["roofline"].get("fused_share_of_cells"),
+                                         "two_steps_per_pass": one["two_steps_per_pass"], "state_finite": one["state_finite"]})
+                        except Exception as e:
+                            rows.append({"slab": r, "error": f"{type(e).__name__}: {e}"})
+                        log("[bench] slab rehearsal:", json.dumps(rows[-1]))
+                    return rows
+                even = [slab.slab_range(Ds, 8, r) for r in range(8)]
+                reh = rehearse_all(even)
+                ss["rehearsal_8_even_split"] = reh
+                if all("ms_per_step" in x for x in reh):
+                    ss["projected_efficiency_8_even_split"] = round(ss["ms_per_step"] / (8 * max(x["ms_per_step"] for x in reh)), 4)
+                    if not args.no_balance:
+                        cut = slab.balanced_ranges(Ds, even, [x["ms_per_step"] for x in reh])
+                        reh = rehearse_all(cut) if cut != even else reh
+                    ss["rehearsal_8"] = reh
+                    if all("ms_per_step" in x for x in reh):
+                        t8 = max(x["ms_per_step"] for x in reh)
+                        ss["projected_ms_per_step_8"] = t8
+                        ss["projected_efficiency_8"] = round(ss["ms_per_step"] / (8 * t8), 4)
+                        ss["projection_note"] = ("T1 / (8 x the slowest of the eight slabs an 8-GPU run would hold), each stepped on this one "
+                                                 "GPU with its RCCL ring closed on itself, slabs cut for equal measured cost as the N > 1 "
+                                                 "run cuts them; no xGMI transfer is in it")
             if out is not None:
                 out["strong_scaling"] = ss
                 log("[bench] strong scaling:", json.dumps(ss))

@@ -35,7 +35,7 @@
 #endif
 
 struct FusedGrid {
-    int nbx, nby, nbz;      // 64-cell tiles in x, TY-row tiles in y, pieces an unobstructed tile column is cut into in z
+    int nbx, nby;           // 64-cell tiles in x, tiles of at most TY rows in y (rows dealt evenly: fused_prepare())
     int nblocks;            // workgroups of a launch: 8 x the longest of the eight XCD ranges of the block list
     int y_first, y_end;     // rows [y_first, y_end) take the fused path (y_first >= 2, y_end <= H - 2)
     int zl_first, zl_end;   // local layers (ghost offset included) the blocks lie in: [3, D - 1)
@@ -203,7 +203,7 @@ template <int PRESET, int TY, int STAGE, int NBUF, int OBST>
 __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
                                                           const unsigned long long* __restrict__ blocks,
                                                           const unsigned* __restrict__ nbw, Geo g, Params p,
-                                                          FusedGrid fg) {
+                                                          FusedGrid fg, unsigned long long* __restrict__ stamps) {
     constexpr int ROWS = TY + 2;
     constexpr int PLANE = ROWS * F2_LCOLS;
     constexpr int EXCH = 16 * PLANE;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     // columns, the second 128-byte line of an x-shifted load), so every XCD takes ONE contiguous range of the
     // list: the lines two tiles share are then fetched from HBM once instead of once per L2, and every XCD
     // still gets the same number of blocks whatever the obstacles leave eligible.
-    int bx, by, zs, ze;                                          // second step: local layers [zs, ze)
+    int bx, y0, tyn, zs, ze;                                     // rows [y0, y0 + tyn); second step: local layers [zs, ze)
+    bool blk_clean;
     {
         // blocks[0..8]: where each XCD's range of the list starts (ranges of equal WORK, not equal count: the
         // runs an obstacle leaves differ in length); workgroup n of XCD x takes entry n of range x, a workgroup
@@ -226,17 +227,21 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         const unsigned long long e = blocks[9 + first + nth];
         // the entry is the same for the whole workgroup: keep what is derived from it in scalar registers
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+        // x tile : 12 | first row : 16 | rows : 4 | first second-step layer : 16 | layers : 15 | clean : 1
         bx = (int)(lo & 0xfffu);
-        by = (int)((lo >> 12) & 0xfffu);
-        zs = (int)((lo >> 24) | ((hi & 0xfffu) << 8));
+        y0 = (int)((lo >> 12) & 0xffffu);
+        tyn = (int)(lo >> 28);
+        zs = (int)(hi & 0xffffu);
         // (the host never lets a block run past zl_end; written as a min() the compiler cannot derive a minimum trip
         // count of the layer loop from the entry's layout, which made it peel the loop and spill 18 registers)
-        ze = min(zs + (int)(hi >> 12), fg.zl_end);
+        ze = min(zs + (int)((hi >> 16) & 0x7fffu), fg.zl_end);
+        // bit 63: no solid cell within reach of the block (OBST form: it then reads no neighbour words at all)
+        blk_clean = (hi >> 31) != 0u;
     }
+    if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int role = f2_role<TY>(wave);
-    const int x0 = bx * 64, y0 = fg.y_first + by * TY;
-    const int tyn = min(TY, fg.y_end - y0);                     // rows of this tile that exist (the last tile may be short)
+    const int x0 = bx * 64;
 
     int x, r;
     bool active;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     const unsigned nb_cell = (unsigned)((active ? y : y0) * g.Wp + (active ? x : x0));
     const unsigned* nb_base = nbw + (long long)(zs - 3) * g.H * g.Wp;
     auto nb_of = [&](int L) -> unsigned {
-        if (!OBST || !active) return 0u;
+        if (!OBST || !active || blk_clean) return 0u;
         return nb_base[(unsigned)(L - (zs - 3)) * (unsigned)(g.H * g.Wp) + nb_cell];
     };
 
@@ -335,4 +340,5 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         for (int k = 0; k < Q; k++) { below[k] = cur[k]; cur[k] = above[k]; }
         nb_cur = nb_above; nb_above = nb_next; nb_next = nb_next2;
     }
+    if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }

@@ -55,7 +55,8 @@ __global__ void k_halo_unpack(float* __restrict__ f, const float* __restrict__ m
 }
 
 __global__ void k_halo_unpack2(float* __restrict__ f, const float* __restrict__ from_below,
-                               const float* __restrict__ from_above, Geo g) {
+                               const float* __restrict__ from_above, Geo g, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);   // between the two exchanges of a pair: runs beside k_fused2, which the next boundary step waits behind
     const int side = blockIdx.y / 6;
     const float* msg = side ? from_above : from_below;
     if (!msg) return;

@@ -281,7 +281,9 @@ struct GatherAll<PRESET, -1> {
 // workgroups that sit side by side in one row land on different XCDs and the cache line their
 // x-shifted loads share at the seam is fetched into two L2s.  With ZORDER_XCD the launch order is
 // re-read so that each XCD gets whole rows: of every 8 consecutive rows of workgroups, row j goes to XCD j.
-constexpr int ZORDER_REVERSE = 1, ZORDER_XCD = 2;
+// ZORDER_PRIO: the launch runs beside k_fused2 (the boundary layers and the rim of a pair of steps) and something waits
+// for it: its waves raise their issue priority over the long kernel's (s_setprio)
+constexpr int ZORDER_REVERSE = 1, ZORDER_XCD = 2, ZORDER_PRIO = 4;
 struct TileId {
     int xs, y, lane, bz;
 };
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const unsigned long long* __restrict__ tile_list) {
     TileId t;
     int zl;
+    if ((MODE == 2 || MODE == 4) && (zrev & ZORDER_PRIO)) __builtin_amdgcn_s_setprio(3);
     if (MODE == 4) {
         // one list entry per wave: xs | y << 16 | zl << 40 (host side: fused_prepare() in lbm_hip.hip); ~0 pads the list
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

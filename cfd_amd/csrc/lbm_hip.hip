@@ -26,6 +26,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -117,6 +119,8 @@ struct lbm_ctx {
     int f2_ty = 12, f2_stage = 1, f2_nbuf = 1;  // kernel variant: measured best of the compiled ones (profiles/r02_tuning.md) (LBM_FUSED_VARIANT="TY,STAGE,NBUF")
     int f2_zsplit = 0;             // LBM_FUSED_ZSPLIT: z chunks per tile column (0 = chosen by fused_prepare)
     bool f2_obst = true;           // LBM_FUSED_OBST=0: blocks keep clear of obstacles (round-2 first form)
+    int f2_ny = 0;                 // LBM_FUSED_NY: y tiles per tile column (0 = chosen by fused_prepare)
+    unsigned long long* f2_stamps = nullptr;   // lbm_fused_chain_stamps(): start / end clock of every workgroup of one launch
     bool f2_obst_blocks = false;   // some block of the current list holds or touches solid cells
     unsigned* f2_nbw = nullptr;    // one word per cell: which directions bounce back from a solid neighbour (k_f2_nb_words)
     FusedGrid fg{};
@@ -135,6 +139,8 @@ struct lbm_ctx {
     // a PAIR of steps on a z-slab (lbm_pair_*): 0 idle, 1 boundary layers of the first step issued, 2 interior issued,
     // 3 boundary layers of the second step issued
     int pair_phase = 0;
+    bool pair_rim_stream = true;   // LBM_PAIR_RIM_STREAM=0: the rim's launches of a pair stay on the context's stream
+    bool side_prio = true;         // LBM_SIDE_PRIO=0: the short kernels beside k_fused2 do not raise their waves' priority
     hipEvent_t ev_pair_b1 = nullptr, ev_pair_r1 = nullptr;
     bool pair_last = false;        // the last update was a pair: the previous buffer is TWO steps old (no rho/u on demand)
     std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
@@ -156,6 +162,8 @@ constexpr int MAX_DEVICES = 64;
 static void* g_scratch_ptr[MAX_DEVICES] = {nullptr};
 // once per device, with that device current
 static hipError_t resolve_scratch(int dev) {
+    static std::mutex lock;                        // contexts may be created from several host threads at once
+    std::lock_guard<std::mutex> hold(lock);
     if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
     if (g_scratch_ptr[dev]) return hipSuccess;
     void* ptr = nullptr;
@@ -278,7 +286,8 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
         grid = dim3((unsigned)(ntiles / 4));
     }
     if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
-    const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0);
+    const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0) |
+                     (((MODE == 2 || MODE == 4) && c->side_prio && c->fused_usable) ? ZORDER_PRIO : 0);
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
     hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
                        c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top,     \
@@ -468,7 +477,7 @@ static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout)
         attr_set[c->device] = true;
     }
     hipLaunchKernelGGL(kern, dim3(c->fg.nblocks), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
-                       c->f2_nbw, c->g, c->p, c->fg);
+                       c->f2_nbw, c->g, c->p, c->fg, c->f2_stamps);
     return hipGetLastError();
 }
 template <int PRESET, int TY, int STAGE, int NBUF>
@@ -522,6 +531,7 @@ static int fused_prepare(lbm_ctx* c) {
     if (max_chunk < 1) return LBM_OK;
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    if (const char* t = getenv("LBM_FUSED_NCU")) ncu = std::max(8, atoi(t));   // tests / probes: plan for another CU count
 
     // tile flags -> host
     const long long ntiles = (long long)g.D * g.H * g.Wt;
@@ -548,11 +558,49 @@ static int fused_prepare(lbm_ctx* c) {
     fg.y_end = g.H - 2;
     while (fg.y_end > g.H - std::min(g.H / 4, 8) && !row_clean(fg.y_end)) fg.y_end--;
     if (fg.y_end - fg.y_first < 1) return LBM_OK;
-    fg.nby = (fg.y_end - fg.y_first + TY - 1) / TY;
-    if (fg.nby > 4096) return LBM_OK;                               // block list entry: 12 bits for the y tile
     fg.zl_first = g.slab ? 2 : 3;                                   // widest possible range of second-step layers:
     fg.zl_end = g.slab ? g.D : g.D - 1;                             // a slab's outer layers are its boundary layers, a domain's its walls
+    if (g.H >= (1 << 16) || g.D + 2 >= (1 << 15)) return LBM_OK;    // block list entry: 16 bits each for the first row and first layer, 15 for the layers
 
+    // ---- the plan: y tiles, runs, blocks, launch order ------------------------------------------------------------
+    // A tile takes at most TY rows and a CU holds one workgroup (132 KB of LDS), so a launch runs in rounds of `ncu`
+    // blocks, and a part-filled last round costs as much as a full one.  Taller tiles and longer blocks are not
+    // always better: 1024 x 512 x 64 (one of eight slabs of configs[3]) has 508 rows = 43 tiles of 12 = 688 tile
+    // columns = 2.7 rounds on 256 CUs, while 47-48 tiles of 10-11 rows are three full rounds of cheaper layers; and
+    // around an obstacle the number of blocks depends on where the runs break (766 blocks are three rounds, 770
+    // four).  So the plan is SEARCHED: for every candidate number of y tiles (rows dealt evenly) the runs are found,
+    // for every candidate piece length the blocks are cut, ordered and dealt to the XCDs, and the launch is played
+    // through (every XCD hands its range of the list, in order, to whichever of its CUs is free) with a block
+    // costing (layers + 2 lead-in layers) x (rows + row_cost: the waves that do first steps only, the barriers);
+    // the candidate whose launch ends first wins.
+    const int rows = fg.y_end - fg.y_first, layers_all = fg.zl_end - fg.zl_first;
+    if (layers_all < 1) return LBM_OK;
+    double row_cost = 4.0;   // (10 against 11 rows: 6 % less time per layer, tools/chain_spread.py)
+    if (const char* t = getenv("LBM_FUSED_ROWCOST")) row_cost = atof(t);
+    constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
+    struct YTile { int y0, n; };
+    struct Run { int bx, by, a, len; size_t dirty; };   // dirty: where its layers' obstacle counts start in Plan::dirty
+    struct Block { unsigned bx, by, zs, len, clean; };   // clean: no solid cell within reach of its first steps
+    struct Plan {
+        std::vector<YTile> ytile;
+        std::vector<Run> runs;
+        std::vector<int> dirty;          // per run: running count of its first-step layers (a .. a + len + 1) that an obstacle reaches
+        std::vector<Block> all;          // in launch order: eight ranges, one per XCD
+        size_t range[9] = {0};
+        bool obst_blocks = false;
+        int zchunk = 0;
+        double makespan = 1e300, covered = 0.0;
+    };
+    const bool obst = c->f2_obst;
+
+    // rows dealt evenly, the taller tiles spread over the height (and so over the XCDs' ranges)
+    auto make_tiles = [&](int ny, Plan& pl) {
+        pl.ytile.resize((size_t)ny);
+        for (int i = 0, y = fg.y_first; i < ny; i++) {
+            pl.ytile[(size_t)i] = {y, (int)((long long)rows * (i + 1) / ny - (long long)rows * i / ny)};
+            y += pl.ytile[(size_t)i].n;
+        }
+    };
     // Runs: for every tile column (x tile, y tile) the maximal runs of layers a block can take.  Everything the
     // first step touches -- one more tile in x, one more row in y and one more layer in z on every side -- must
     // be free of the domain's walls (the kernel has no wall rows / layers; rows are kept off them by y_first /
@@ -561,102 +609,183 @@ static int fused_prepare(lbm_ctx* c) {
     // from a solid cell's frozen values); without it every tile in reach must be an interior tile (flag 0).
     // A run of usable layers [a, b] carries second steps for the layers a+1 .. b-1; layers in which most of the
     // block is solid are not worth a pass and end a run as well.
-    constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
-    struct Run { int bx, by, a, len; };
-    std::vector<std::vector<Run>> runs_of((size_t)fg.nby);
-    std::vector<unsigned char> touches((size_t)fg.nby, 0);
-    const bool obst = c->f2_obst;
+    auto tiles_clean = [&](const Plan& pl, int bx, int by, int z_first, int z_last) {   // 0-based layers of first steps
+        const int y0 = pl.ytile[(size_t)by].y0, tyn = pl.ytile[(size_t)by].n;
+        for (int z = z_first; z <= z_last; z++)
+            for (int y = y0 - 1; y <= y0 + tyn; y++)
+                for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
+                    if (fl[tile(xs, y, z)] != 0) return false;
+        return true;
+    };
+    auto find_runs = [&](Plan& pl) {
+        const int ny = (int)pl.ytile.size();
+        std::vector<std::vector<Run>> runs_of((size_t)ny);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int by = 0; by < fg.nby; by++) {
-        const int y0 = fg.y_first + by * TY, tyn = std::min(TY, fg.y_end - y0);
-        for (int bx = 0; bx < fg.nbx; bx++) {
-            const bool outlet_tile = c->preset == LBM_PRESET_WIND_TUNNEL_REF && bx == g.Wt - 1;
-            auto clean = [&](int z) {
-                for (int y = y0 - 1; y <= y0 + tyn; y++)
-                    for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
-                        if (fl[tile(xs, y, z)] != 0) return false;
-                return true;
-            };
-            auto usable = [&](int z) {   // as a layer of first steps
-                if (!obst || outlet_tile) return clean(z);
-                const int zg = z + g.z0;
-                return zg > 0 && zg < g.Dg - 1;
-            };
-            auto wanted = [&](int z) {   // as a layer of second steps
-                if (!obst || outlet_tile) return true;
-                int fluid = 0;
-                for (int y = y0; y < y0 + tyn; y++) fluid += fl[tile(bx, y, z)] != 2;
-                return fluid * 3 >= tyn;   // (thresholds from 1 % to 100 % of the rows move configs[2] by under 1 %)
-            };
-            int z = 0;
-            while (z < g.D) {
-                if (!usable(z)) { z++; continue; }
-                const int a = z;
-                while (z < g.D && usable(z)) z++;
-                const int b = z - 1;                                 // usable layers [a, b] (0-based): second steps a+1 .. b-1
-                int s = a + 1;
-                while (s <= b - 1) {
-                    if (!wanted(s)) { s++; continue; }
-                    int e = s;
-                    while (e + 1 <= b - 1 && wanted(e + 1)) e++;
-                    if (e - s + 1 >= MIN_LAYERS) {
-                        runs_of[(size_t)by].push_back({bx, by, s - 1, e - s + 1});
-                        if (obst && !touches[(size_t)by])
-                            for (int zz = s - 1; zz <= e + 1 && !touches[(size_t)by]; zz++)
-                                if (!clean(zz)) touches[(size_t)by] = 1;
+        for (int by = 0; by < ny; by++) {
+            const int y0 = pl.ytile[(size_t)by].y0, tyn = pl.ytile[(size_t)by].n;
+            for (int bx = 0; bx < fg.nbx; bx++) {
+                const bool outlet_tile = c->preset == LBM_PRESET_WIND_TUNNEL_REF && bx == g.Wt - 1;
+                auto clean = [&](int z) { return tiles_clean(pl, bx, by, z, z); };
+                auto usable = [&](int z) {   // as a layer of first steps
+                    if (!obst || outlet_tile) return clean(z);
+                    const int zg = z + g.z0;
+                    return zg > 0 && zg < g.Dg - 1;
+                };
+                auto wanted = [&](int z) {   // as a layer of second steps
+                    if (!obst || outlet_tile) return true;
+                    int fluid = 0;
+                    for (int y = y0; y < y0 + tyn; y++) fluid += fl[tile(bx, y, z)] != 2;
+                    return fluid * 3 >= tyn;   // (thresholds from 1 % to 100 % of the rows move configs[2] by under 1 %)
+                };
+                int z = 0;
+                while (z < g.D) {
+                    if (!usable(z)) { z++; continue; }
+                    const int a = z;
+                    while (z < g.D && usable(z)) z++;
+                    const int b = z - 1;                                 // usable layers [a, b] (0-based): second steps a+1 .. b-1
+                    int s = a + 1;
+                    while (s <= b - 1) {
+                        if (!wanted(s)) { s++; continue; }
+                        int e = s;
+                        while (e + 1 <= b - 1 && wanted(e + 1)) e++;
+                        if (e - s + 1 >= MIN_LAYERS) runs_of[(size_t)by].push_back({bx, by, s - 1, e - s + 1, 0});
+                        s = e + 1;
                     }
-                    s = e + 1;
                 }
             }
         }
-    }
-    c->f2_obst_blocks = false;
-    for (unsigned char t : touches) c->f2_obst_blocks = c->f2_obst_blocks || t;
-    std::vector<Run> runs;
-    for (auto& v : runs_of) runs.insert(runs.end(), v.begin(), v.end());
-    if (runs.empty()) return LBM_OK;
-
-    // Layers per block.  A block costs its layers + two lead-in layers of first steps; the launch takes as many
-    // rounds as its blocks need at one workgroup per CU.  Pick the piece length with the least rounds x (layers + 2).
-    int zchunk = 0;
-    if (c->f2_zsplit > 0) {
-        zchunk = std::min(max_chunk, std::max(MIN_LAYERS, (fg.zl_end - fg.zl_first + c->f2_zsplit - 1) / c->f2_zsplit));
-    } else {
-        double best = 1e300;
-        int longest = 0;
-        for (const Run& r : runs) longest = std::max(longest, r.len);
-        for (int zc = std::min(longest, max_chunk); zc >= MIN_LAYERS; zc--) {
-            long long blocks = 0;
-            int piece_max = 0;
-            for (const Run& r : runs) {
-                const int pieces = (r.len + zc - 1) / zc;
-                blocks += pieces;
-                piece_max = std::max(piece_max, (r.len + pieces - 1) / pieces);
+        pl.runs.clear();
+        for (auto& v : runs_of) pl.runs.insert(pl.runs.end(), v.begin(), v.end());
+        // which first-step layers of a run an obstacle reaches: a block none of whose layers is reached reads no
+        // neighbour words (k_fused2.h), and a launch without any such layer takes the plain form of the kernel
+        size_t total = 0;
+        for (Run& r : pl.runs) { r.dirty = total; total += (size_t)r.len + 3; }
+        pl.dirty.assign(total, 0);
+        bool any = false;
+        if (obst) {
+#pragma omp parallel for schedule(dynamic, 16) reduction(|| : any)
+            for (long long i = 0; i < (long long)pl.runs.size(); i++) {
+                const Run& r = pl.runs[(size_t)i];
+                int* d = pl.dirty.data() + r.dirty;
+                for (int j = 0; j < r.len + 2; j++) d[j + 1] = d[j] + (tiles_clean(pl, r.bx, r.by, r.a + j, r.a + j) ? 0 : 1);
+                any = any || d[r.len + 2] > 0;
             }
-            const double cost = (double)((blocks + ncu - 1) / ncu) * (piece_max + 2);
-            if (cost < best - 1e-9) { best = cost; zchunk = zc; }
         }
-    }
-    if (zchunk < 1) return LBM_OK;
-    fg.zchunk = zchunk;
-    fg.nbz = (fg.zl_end - fg.zl_first + zchunk - 1) / zchunk;
+        pl.obst_blocks = any;
+    };
+    // blocks of at most `zchunk` layers, in launch order, and the launch played through
+    auto block_cost = [&](const Plan& pl, const Block& k) {
+        return (double)(k.len + 2) * (pl.ytile[k.by].n + row_cost) * ((pl.obst_blocks && !k.clean) ? 1.06 : 1.0);
+    };
+    auto cut_blocks = [&](Plan& pl, int zchunk) {
+        pl.zchunk = zchunk;
+        pl.all.clear();
+        pl.covered = 0.0;
+        for (const Run& r : pl.runs) {
+            const int pieces = (r.len + zchunk - 1) / zchunk;
+            const int per = (r.len + pieces - 1) / pieces;
+            for (int s0 = 0; s0 < r.len; s0 += per) {
+                const int n = std::min(per, r.len - s0);
+                const int zs = r.a + 1 + s0 + 1;                     // local layer index (ghost offset): z + 1
+                const int* d = pl.dirty.data() + r.dirty;            // first steps: 0-based layers zs - 2 .. zs - 1 + n = run layers s0 .. s0 + n + 1
+                pl.all.push_back({(unsigned)r.bx, (unsigned)r.by, (unsigned)zs, (unsigned)n,
+                                  (unsigned)(pl.obst_blocks && d[s0 + n + 2] - d[s0] == 0 ? 1 : 0)});
+                pl.covered += (double)n * pl.ytile[(size_t)r.by].n;
+            }
+        }
+        // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
+        // (and the contiguous ranges the XCDs take, k_fused2.h) are neighbours in space
+        std::stable_sort(pl.all.begin(), pl.all.end(), [&](const Block& p, const Block& q) {
+            const unsigned cp = (p.zs - 1) / (unsigned)zchunk, cq = (q.zs - 1) / (unsigned)zchunk;
+            if (cp != cq) return cp < cq;
+            if (p.by != q.by) return p.by < q.by;
+            return p.bx < q.bx;
+        });
+        // Eight contiguous ranges of the list, one per XCD, of equal cost; within a range the dear blocks go first so
+        // that the cheap ones fill the tail.  Without obstacles all blocks of a tile height are alike and this is
+        // the list cut into eight equal parts in its own order.
+        double total = 0.0, done = 0.0;
+        for (const Block& k : pl.all) total += block_cost(pl, k);
+        size_t at = 0;
+        const int per_xcd = std::max(1, ncu / 8);
+        pl.makespan = 0.0;
+        std::vector<double> free_at;
+        for (int xcd = 0; xcd < 8; xcd++) {
+            const size_t first = at;
+            const double target = total * (xcd + 1) / 8;
+            while (at < pl.all.size() && (xcd == 7 || done + block_cost(pl, pl.all[at]) / 2 <= target)) { done += block_cost(pl, pl.all[at]); at++; }
+            std::stable_sort(pl.all.begin() + (long)first, pl.all.begin() + (long)at,
+                             [&](const Block& p, const Block& q) { return block_cost(pl, p) > block_cost(pl, q); });
+            pl.range[xcd] = first;
+            pl.range[xcd + 1] = at;
+            // the XCD's CUs take its blocks in list order, each when it is free (a min-heap of the times they are free at)
+            free_at.assign((size_t)per_xcd, 0.0);
+            for (size_t i = first; i < at; i++) {
+                std::pop_heap(free_at.begin(), free_at.end(), std::greater<double>());
+                free_at.back() += block_cost(pl, pl.all[i]);
+                std::push_heap(free_at.begin(), free_at.end(), std::greater<double>());
+            }
+            pl.makespan = std::max(pl.makespan, *std::max_element(free_at.begin(), free_at.end()));
+        }
+    };
 
-    struct Block { unsigned bx, by, zs, len; };
-    std::vector<Block> all;
+    Plan best;
+    {
+        const int ny_min = (rows + TY - 1) / TY;
+        std::vector<int> ny_candidates;
+        if (c->f2_ny > 0) ny_candidates.push_back(std::min(rows, std::max(ny_min, c->f2_ny)));
+        else for (int n = ny_min; n <= std::min(rows, ny_min + ny_min / 2 + 1); n++) ny_candidates.push_back(n);
+        // what a candidate leaves to the rim costs two single steps there: about 2.5 x its share of a fused pass
+        const double full = (double)rows * layers_all * fg.nbx;
+        double best_score = 1e300;
+        int best_ny = 0, best_zc = 0;
+        for (int ny : ny_candidates) {
+            Plan pl;
+            make_tiles(ny, pl);
+            find_runs(pl);
+            if (pl.runs.empty()) continue;
+            int longest = 0;
+            for (const Run& r : pl.runs) longest = std::max(longest, r.len);
+            std::vector<int> zcs;
+            if (c->f2_zsplit > 0) {
+                zcs.push_back(std::min(max_chunk, std::max(MIN_LAYERS, (layers_all + c->f2_zsplit - 1) / c->f2_zsplit)));
+            } else {
+                for (int pieces = 1; pieces <= 16; pieces++) {
+                    const int zc = std::min(max_chunk, (longest + pieces - 1) / pieces);
+                    if (zc < MIN_LAYERS) break;
+                    if (zcs.empty() || zcs.back() != zc) zcs.push_back(zc);
+                }
+            }
+            for (int zc : zcs) {
+                cut_blocks(pl, zc);
+                const double score = pl.makespan + 2.5 * (full - pl.covered) * (TY + row_cost) / TY / ncu;
+                if (const char* dbg = getenv("LBM_FUSED_DEBUG"))
+                    if (dbg[0] == '3') fprintf(stderr, "[fused]   candidate: %d y tiles, pieces of %d layers: %zu blocks, launch %.0f, covered %.0f of %.0f, score %.0f\n",
+                                               ny, zc, pl.all.size(), pl.makespan, pl.covered, full, score);
+                if (score < best_score * (1.0 - 1e-9)) { best_score = score; best_ny = ny; best_zc = zc; }
+            }
+        }
+        if (best_ny == 0) return LBM_OK;
+        make_tiles(best_ny, best);
+        find_runs(best);
+        cut_blocks(best, best_zc);
+    }
+    if (best.all.empty()) return LBM_OK;
+    const std::vector<YTile>& ytile = best.ytile;
+    const std::vector<Run>& runs = best.runs;
+    const std::vector<Block>& all = best.all;
+    const int zchunk = best.zchunk;
+    fg.nby = (int)ytile.size();
+    fg.zchunk = zchunk;
+    c->f2_obst_blocks = best.obst_blocks;
+
     std::vector<unsigned char> covered((size_t)ntiles, 0);
     long long fused_cells = 0;
-    for (const Run& r : runs) {
-        const int y0 = fg.y_first + r.by * TY, tyn = std::min(TY, fg.y_end - y0);
-        const int pieces = (r.len + zchunk - 1) / zchunk;
-        const int per = (r.len + pieces - 1) / pieces;
-        for (int s0 = 0; s0 < r.len; s0 += per) {
-            const int n = std::min(per, r.len - s0);
-            const int zs = r.a + 1 + s0 + 1;                         // local layer index (ghost offset): z + 1
-            all.push_back({(unsigned)r.bx, (unsigned)r.by, (unsigned)zs, (unsigned)n});
-            for (int zz = zs - 1; zz < zs - 1 + n; zz++)
-                for (int y = y0; y < y0 + tyn; y++) covered[tile(r.bx, y, zz)] = 1;
-            fused_cells += (long long)std::min(64, g.W - r.bx * 64) * tyn * n;
-        }
+    for (const Block& k : all) {
+        const int y0 = ytile[k.by].y0, tyn = ytile[k.by].n;
+        for (int zz = (int)k.zs - 1; zz < (int)(k.zs - 1 + k.len); zz++)
+            for (int y = y0; y < y0 + tyn; y++) covered[tile((int)k.bx, y, zz)] = 1;
+        fused_cells += (long long)std::min(64, g.W - (int)k.bx * 64) * tyn * k.len;
     }
     if (c->f2_obst_blocks) {   // fused_cells counts cells the kernel UPDATES: take the solid cells inside the blocks off
         std::vector<unsigned long long> mw((size_t)(g.D + 2) * g.H * g.Wm);
@@ -674,49 +803,35 @@ static int fused_prepare(lbm_ctx* c) {
     if (getenv("LBM_FUSED_DEBUG")) {   // planning summary for tools/fused_bench.py
         long long f0 = 0, f1 = 0, f2 = 0;
         for (long long i = 0; i < ntiles; i++) { f0 += fl[(size_t)i] == 0; f1 += fl[(size_t)i] == 1; f2 += fl[(size_t)i] == 2; }
-        fprintf(stderr, "[fused] %dx%dx%d TY %d rows [%d,%d) layers [%d,%d) tiles: %lld interior %lld boundary %lld solid; %zu runs, zchunk %d, %zu blocks, fused %.1f %% of cells\n",
-                g.W, g.H, g.D, TY, fg.y_first, fg.y_end, fg.zl_first, fg.zl_end, f0, f1, f2, runs.size(), zchunk, all.size(),
-                100.0 * (double)fused_cells / (double)cells(c));
+        size_t nclean = 0;
+        double work = 0.0;
+        for (const Block& k : all) { nclean += k.clean; work += block_cost(best, k); }
+        fprintf(stderr, "[fused] %dx%dx%d TY %d rows [%d,%d) in %d y tiles, layers [%d,%d) tiles: %lld interior %lld boundary %lld solid; %zu runs, zchunk %d, %zu blocks (%zu clean of obstacles), "
+                "planned launch %.0f against %.0f for perfectly spread work, fused %.1f %% of cells\n",
+                g.W, g.H, g.D, TY, fg.y_first, fg.y_end, fg.nby, fg.zl_first, fg.zl_end, f0, f1, f2, runs.size(), zchunk, all.size(), nclean,
+                best.makespan, work / (8 * std::max(1, ncu / 8)), 100.0 * (double)fused_cells / (double)cells(c));
         std::vector<long long> per_by((size_t)fg.nby, 0);
         for (const Run& r : runs) per_by[(size_t)r.by] += r.len;
-        for (int by = 0; by < fg.nby; by++)
-            fprintf(stderr, "[fused]   y tile %d (rows %d..): %.1f %% of its column-layers\n", by, fg.y_first + by * TY,
-                    100.0 * (double)per_by[(size_t)by] / ((double)fg.nbx * (fg.zl_end - fg.zl_first)));
+        if (getenv("LBM_FUSED_DEBUG")[0] == '2')
+            for (int by = 0; by < fg.nby; by++)
+                fprintf(stderr, "[fused]   y tile %d (rows %d..%d): %.1f %% of its column-layers\n", by, ytile[(size_t)by].y0, ytile[(size_t)by].y0 + ytile[(size_t)by].n - 1,
+                        100.0 * (double)per_by[(size_t)by] / ((double)fg.nbx * (fg.zl_end - fg.zl_first)));
     }
     if (fused_cells * 4 < cells(c)) return LBM_OK;                  // under a quarter of the domain: not worth the rim's overhead
-    // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
-    // (and the contiguous ranges the XCDs take, k_fused2.h) are neighbours in space; long blocks first within
-    // a range so that the short ones fill the tail
-    std::stable_sort(all.begin(), all.end(), [&](const Block& p, const Block& q) {
-        const unsigned cp = (p.zs - 1) / (unsigned)fg.zchunk, cq = (q.zs - 1) / (unsigned)fg.zchunk;
-        if (cp != cq) return cp < cq;
-        if (p.by != q.by) return p.by < q.by;
-        return p.bx < q.bx;
-    });
-    // Eight contiguous ranges of the list, one per XCD, of equal work (a block costs its layers + the two lead-in
-    // layers); within a range the long blocks go first so that the short ones fill the tail.  Without obstacles
-    // all blocks are alike and this is the list cut into eight equal parts in its own order.
     std::vector<unsigned long long> blocks(9, 0ull);
     {
-        long long total = 0;
-        for (const Block& k : all) total += k.len + 2;
-        size_t at = 0;
-        long long done = 0;
         size_t longest = 0;
         for (int xcd = 0; xcd < 8; xcd++) {
-            const size_t first = at;
-            const long long target = total * (xcd + 1) / 8;
-            while (at < all.size() && (xcd == 7 || done + (long long)(all[at].len + 2) / 2 <= target)) { done += all[at].len + 2; at++; }
-            std::stable_sort(all.begin() + (long)first, all.begin() + (long)at, [](const Block& p, const Block& q) { return p.len > q.len; });
-            blocks[(size_t)xcd] = first;
-            blocks[(size_t)xcd + 1] = at;
-            longest = std::max(longest, at - first);
+            blocks[(size_t)xcd] = best.range[xcd];
+            blocks[(size_t)xcd + 1] = best.range[xcd + 1];
+            longest = std::max(longest, best.range[xcd + 1] - best.range[xcd]);
         }
         fg.nblocks = (int)(8 * longest);
     }
     blocks.reserve(9 + all.size());
     for (const Block& k : all)
-        blocks.push_back((unsigned long long)k.bx | ((unsigned long long)k.by << 12) | ((unsigned long long)k.zs << 24) | ((unsigned long long)k.len << 44));
+        blocks.push_back((unsigned long long)k.bx | ((unsigned long long)ytile[k.by].y0 << 12) | ((unsigned long long)ytile[k.by].n << 28) |
+                         ((unsigned long long)k.zs << 32) | ((unsigned long long)k.len << 48) | ((unsigned long long)k.clean << 63));
 
     // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
     // t+1 values from the 26 neighbouring tiles, so the first rim step covers the rim dilated by one tile
@@ -1029,6 +1144,9 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_OBST")) c->f2_obst = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_NY")) c->f2_ny = std::max(0, atoi(t));
+    if (const char* t = getenv("LBM_PAIR_RIM_STREAM")) c->pair_rim_stream = atoi(t) != 0;
+    if (const char* t = getenv("LBM_SIDE_PRIO")) c->side_prio = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_OVERLAP")) c->f2_overlap = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_OVERLAP_PCT")) c->f2_overlap_pct = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_VARIANT")) {
@@ -1114,7 +1232,7 @@ int lbm_destroy(lbm_ctx* c) {
     if (!c->f1_in_alloc0) hipFree(c->f[1]);
     hipFree(c->mask); hipFree(c->flags);
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
-    hipFree(c->ft); hipFree(c->f2_nbw); hipFree(c->f2_blocks); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
+    hipFree(c->ft); hipFree(c->f2_nbw); hipFree(c->f2_blocks); hipFree(c->f2_stamps); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
     for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
     if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
     if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);
@@ -1132,6 +1250,7 @@ int lbm_destroy(lbm_ctx* c) {
 
 int lbm_init(lbm_ctx* c) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_init");
     // the whole allocation: the AA scheme's ghost slots (y = -1, z = -1) lie in the skew region behind
     // the previous plane / in the front guard
     const long long first = -c->guard_floats, last = c->pop_floats;
@@ -1185,6 +1304,7 @@ static int before_mask_change(lbm_ctx* c) {
 
 int lbm_add_solid_rect(lbm_ctx* c, int x, int y, int z, int w, int h, int d) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_add_solid_rect");
     int rc = before_mask_change(c);
     if (rc) return rc;
     const long long nwords = (long long)(c->g.D + 2) * c->g.H * c->g.Wm;
@@ -1196,6 +1316,7 @@ int lbm_add_solid_rect(lbm_ctx* c, int x, int y, int z, int w, int h, int d) {
 
 int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_set_solid_u8");
     if (!mask) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8: mask is null");
     if (n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8: expected %lld cells, got %zu", cells(c), n);
     int rc = before_mask_change(c);
@@ -1218,6 +1339,7 @@ int lbm_set_solid_u8(lbm_ctx* c, const uint8_t* mask, size_t n) {
 // the mask from a dense uint8 array that already lives on the device (cuda_buffer::copy_from_device)
 int lbm_set_solid_u8_device(lbm_ctx* c, const uint8_t* d_mask, size_t n) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_set_solid_u8_device");
     if (!d_mask) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8_device: mask is null");
     if (n != (size_t)cells(c)) return fail(c, LBM_ERR_INVALID, "lbm_set_solid_u8_device: expected %lld cells, got %zu", cells(c), n);
     int rc = before_mask_change(c);
@@ -1242,6 +1364,7 @@ int lbm_device_copy(lbm_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
 
 int lbm_load_mesh(lbm_ctx* c, const char* obj_path) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_load_mesh");
     if (!obj_path) return fail(c, LBM_ERR_INVALID, "lbm_load_mesh: path is null");
     const Geo& g = c->g;
     // host stage, O(triangles): parse, rotate, bounds, auto-scale (lbm_solver.cu:526-538)
@@ -1405,7 +1528,7 @@ int lbm_set_field_window(lbm_ctx* c, int z_begin, int nz) {
 int lbm_set_streams(lbm_ctx* c, void* stream, void* boundary_stream) {
     NEED(c);
     if (!stream) return fail(c, LBM_ERR_INVALID, "lbm_set_streams: stream is null");
-    if (c->split_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_set_streams: a split step is in flight");
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_set_streams: a split step is in flight");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream_b) HIPCHK(c, hipStreamSynchronize(c->stream_b));
     if (c->own_stream) {
@@ -1606,6 +1729,7 @@ int lbm_read_populations(lbm_ctx* c, float* f, size_t n19) {
 
 int lbm_write_populations(lbm_ctx* c, const float* f, size_t n19) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_write_populations");
     if (!f || n19 != (size_t)cells(c) * Q) return fail(c, LBM_ERR_INVALID, "lbm_write_populations: need %lld floats", cells(c) * Q);
     if (c->scheme == LBM_SCHEME_AA) return aa_copy_populations(c, const_cast<float*>(f), false);
     int rc = LBM_OK;
@@ -1650,6 +1774,36 @@ int lbm_device_fields(lbm_ctx* c, float** d_rho, float** d_u, float** d_curl, ui
     return LBM_OK;
 }
 
+// cuda_buffer<T>::copy_from_host / copy_from_device / memset on d_rho, d_u, d_curl (cuda_buffer.cuh:66-77,86-91).  In the
+// reference these arrays are OUTPUTS of step() (lbm_solver.cu:336-337, :655): what a caller writes into them is what
+// readers see until the next step rewrites them, and it never reaches the populations.  Same here: the fields are
+// brought up to date, the first `count` elements overwritten, and the next lbm_step() makes them stale again.
+int lbm_write_field(lbm_ctx* c, int field, const void* src, size_t count, int src_on_device) {
+    NEED(c);
+    if (!src) return fail(c, LBM_ERR_INVALID, "lbm_write_field: source is null");
+    if (field < LBM_FIELD_DENSITY || field > LBM_FIELD_CURL) return fail(c, LBM_ERR_INVALID, "lbm_write_field: unknown field %d", field);
+    const size_t n = (size_t)(field == LBM_FIELD_CURL ? cells(c) : field_cells(c));
+    if (count > n) return fail(c, LBM_ERR_INVALID, "lbm_write_field: %zu elements, the field holds %zu", count, n);
+    int rc = field == LBM_FIELD_CURL ? lbm_compute_curl(c) : refresh_mask_state(c);
+    if (!rc && field != LBM_FIELD_CURL) rc = fields_for_caller(c);
+    if (rc) return rc;
+    void* dst = field == LBM_FIELD_DENSITY ? (void*)c->rho : (field == LBM_FIELD_VELOCITY ? (void*)c->u : (void*)c->curl);
+    const size_t bytes = count * (field == LBM_FIELD_VELOCITY ? sizeof(float4) : sizeof(float));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (field == LBM_FIELD_VELOCITY) c->curl_valid = false;   // a curl asked for now is the curl of what was written
+    return LBM_OK;
+}
+
+// cudaMemcpy(..., cudaMemcpyDeviceToHost) for hosts that do not link the HIP runtime themselves: a prefix of a field
+// whose device pointer lbm_device_fields returned (cuda_buffer<T>::copy_to_host with size < the field's)
+int lbm_copy_to_host(lbm_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    NEED(c);
+    if (!dst || !d_src) return fail(c, LBM_ERR_INVALID, "lbm_copy_to_host: null pointer");
+    if (bytes == 0) return LBM_OK;
+    return read_back(c, dst, d_src, bytes);
+}
+
 int lbm_get_dims(lbm_ctx* c, int* w, int* h, int* d) {
     if (!c) return fail(nullptr, LBM_ERR_INVALID, "null context");
     if (w) *w = c->g.W;
@@ -1667,7 +1821,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->last_timed_ms = c->last_ms;
     out->last_timed_steps = c->last_steps;
     out->last_timed_launches = c->last_launches;
-    out->population_bytes += c->ft ? c->pop_bytes : 0;
+    out->population_bytes += (c->ft && c->fused_usable) ? c->pop_bytes : 0;   // the third buffer, while the fused path uses it
     out->fused_cells = (uint64_t)(c->fused_usable ? c->fused_cells : 0);
     out->rim_cells = (uint64_t)(c->fused_usable ? c->rim_cells : 0);
     out->last_timed_fused_launches = c->last_fused_launches;
@@ -1684,7 +1838,10 @@ int lbm_timer_begin(lbm_ctx* c) {
     c->fused_launches_at_begin = c->fused_launches;
     c->f2_ev_used = 0;
     c->timing = true;
-    if (fused_applies(c) || fused_applies_slab(c)) {  // keep the one-off host work of the fused path out of the timed region as well
+    // keep the one-off host work of the fused path out of the timed region as well -- for callers that use it: a
+    // context that has never launched the fused kernel (single-step frame loops) prepares nothing here (the third
+    // buffer is +50 % population memory)
+    if ((fused_applies(c) || fused_applies_slab(c)) && c->fused_launches > 0) {
         rc = fused_prepare(c);
         if (rc) return rc;
     }
@@ -1711,6 +1868,35 @@ int lbm_timer_end(lbm_ctx* c) {
     // launches beyond the event pool are priced at the mean of the measured ones
     const size_t measured = c->f2_ev_used / 2;
     c->last_fused_ms = measured ? fms * (double)c->last_fused_launches / (double)measured : 0.0;
+    return LBM_OK;
+}
+
+// Diagnostic: ONE k_fused2 launch from the current state into the other buffer with every workgroup writing its start
+// and end clock (s_memrealtime, 100 MHz): how evenly the chains of fused_prepare() end.  The state does not advance;
+// the buffer the launch writes is scratch between steps, but rho/u on demand of the last step are gone.
+int lbm_fused_chain_stamps(lbm_ctx* c, uint64_t* stamps, size_t n, int* nworkgroups) {
+    NEED(c);
+    if (!nworkgroups) return fail(c, LBM_ERR_INVALID, "lbm_fused_chain_stamps: null argument");
+    *nworkgroups = 0;
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_fused_chain_stamps: a split step is in flight");
+    if (!fused_applies(c) && !fused_applies_slab(c)) return LBM_OK;
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = fused_prepare(c);
+    if (rc) return rc;
+    if (!c->fused_usable) return LBM_OK;
+    *nworkgroups = c->fg.nblocks;
+    if (!stamps) return LBM_OK;                                  // size query
+    if (n < 2 * (size_t)c->fg.nblocks) return fail(c, LBM_ERR_INVALID, "lbm_fused_chain_stamps: need %d x 2 stamps", c->fg.nblocks);
+    const size_t bytes = 2 * (size_t)c->fg.nblocks * sizeof(unsigned long long);
+    HIPCHK(c, hipMalloc(&c->f2_stamps, bytes));
+    hipError_t e = hipMemsetAsync(c->f2_stamps, 0, bytes, c->stream);
+    if (e == hipSuccess) e = launch_fused(c, c->f[c->cur], c->f[1 - c->cur]);
+    if (e == hipSuccess) e = hipMemcpyAsync(stamps, c->f2_stamps, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(c->f2_stamps);
+    c->f2_stamps = nullptr;
+    c->prev_touched = true;
+    if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "lbm_fused_chain_stamps: %s", hipGetErrorString(e));
     return LBM_OK;
 }
 
@@ -1766,6 +1952,7 @@ static int halo_args_ok(lbm_ctx* c, int side, const void* p, const char* who) {
 
 int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
     NEED(c);
+    if (c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a pair of steps is in flight: its messages are written by lbm_pair_boundary_* and routed by lbm_halo_unpack_both", "lbm_halo_pack");
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_pack");
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, d_message, true);
@@ -1783,6 +1970,7 @@ int lbm_halo_pack(lbm_ctx* c, int side, float* d_message) {
 
 int lbm_halo_unpack(lbm_ctx* c, int side, const float* d_message) {
     NEED(c);
+    if (c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a pair of steps is in flight: its messages are written by lbm_pair_boundary_* and routed by lbm_halo_unpack_both", "lbm_halo_unpack");
     int rc = halo_args_ok(c, side, d_message, "lbm_halo_unpack");
     if (rc) return rc;
     if (c->scheme == LBM_SCHEME_AA) return aa_halo(c, side, const_cast<float*>(d_message), false);
@@ -1814,6 +2002,7 @@ int lbm_halo_get_mask_layer(lbm_ctx* c, int side, uint8_t* layer, size_t n) {
 
 int lbm_halo_set_mask_ghost(lbm_ctx* c, int side, const uint8_t* layer, size_t n) {
     NEED(c);
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "%s: a split step or a pair of steps is in flight (lbm_step_finish / lbm_pair_finish missing)", "lbm_halo_set_mask_ghost");
     int rc = halo_args_ok(c, side, layer, "lbm_halo_set_mask_ghost");
     if (rc) return rc;
     const size_t wh = (size_t)c->g.W * c->g.H;
@@ -1908,7 +2097,8 @@ int lbm_halo_unpack_both(lbm_ctx* c, const float* d_from_below, const float* d_f
         dst = c->pair_phase == 2 ? c->ft : c->f[1 - c->cur];
         if (c->stream_b) stream = c->stream_b;
     }
-    hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, stream, dst, d_from_below, d_from_above, c->g);
+    hipLaunchKernelGGL(k_halo_unpack2, dim3(blocks_for(per, 256), 12), dim3(256), 0, stream, dst, d_from_below, d_from_above, c->g,
+                       (c->pair_phase && c->side_prio) ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     return LBM_OK;
 }
@@ -1958,17 +2148,35 @@ int lbm_pair_interior(lbm_ctx* c) {
     hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
     const float* in = c->f[c->cur];
     float* out = c->f[1 - c->cur];
+    // The rim's two steps touch no cell the fused kernel touches.  With a boundary stream in use they go to a third,
+    // library-owned stream beside the fused kernel (LBM_PAIR_RIM_STREAM=0: in front of and behind it on the context's
+    // stream, as round 2 had it: 160 us of a 1.43 ms pair at 1024 x 512 x 64, launch gaps included).
+    hipStream_t rs = c->stream;
+    if (c->pair_rim_stream && bs != c->stream) {
+        if (!c->stream_rim) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_main, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2_rim, hipEventDisableTiming));
+        }
+        rs = c->stream_rim;
+        HIPCHK(c, hipEventRecord(c->ev_f2_main, c->stream));          // the previous update, its unpack included
+        HIPCHK(c, hipStreamWaitEvent(rs, c->ev_f2_main, 0));
+    }
     // the rim's first step before the fused kernel: the boundary stream waits for it alone (the second step of the
     // boundary layers pulls from the layers next to them)
-    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[0], c->rim_n[0]);
+    int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rs, c->rim_list[0], c->rim_n[0]);
     if (rc) return rc;
-    if (bs != c->stream) HIPCHK(c, hipEventRecord(c->ev_pair_r1, c->stream));
+    if (bs != c->stream) HIPCHK(c, hipEventRecord(c->ev_pair_r1, rs));
     rc = launch_fused_timed(c, in, out);
     if (rc) return rc;
     // the rim's second step pulls from the boundary layers' first step
-    if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pair_b1, 0));
-    rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, nullptr, c->rim_list[1], c->rim_n[1]);
+    if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(rs, c->ev_pair_b1, 0));
+    rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rs, c->rim_list[1], c->rim_n[1]);
     if (rc) return rc;
+    if (rs != c->stream) {   // whatever follows on the context's stream sees the rim's results
+        HIPCHK(c, hipEventRecord(c->ev_f2_rim, rs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
+    }
     c->pair_phase = 2;
     return LBM_OK;
 }

@@ -65,27 +65,24 @@ class hip_buffer {
         if (!m_ctx || size > m_size || size > m_full) return;
         if (size == m_full) {
             read_all(host_data);
-        } else {
-            std::vector<T> tmp(m_full);
-            read_all(tmp.data());
-            std::memcpy(host_data, tmp.data(), size * sizeof(T));
+        } else if (size > 0) {   // a prefix: straight from the device array, no whole-field temporary
+            const T* src = get_data();
+            if (src) LBM_CHECK(m_ctx, lbm_copy_to_host(m_ctx, host_data, src, size * sizeof(T)));
         }
     }
     // cuda_buffer.cuh:93-98: blocking device-to-device copy of `size` elements out of the field (what a
     // renderer does with get_velocity() / get_solid_mask()); silently skipped if size > m_size
-    void copy_to_device(T* device_ptr, size_t size) {
+    void copy_to_device(T* device_ptr, size_t size) const {
         if (!m_ctx || size > m_size || size > m_full) return;
         const T* src = get_data();
         if (src) LBM_CHECK(m_ctx, lbm_device_copy(m_ctx, device_ptr, src, size * sizeof(T)));
     }
-    // cuda_buffer.cuh:86-91; like copy_from_host only the whole solid mask is an input here
+    // cuda_buffer.cuh:86-91.  The solid mask is an input of the solver and is replaced as a whole (lbm_solver.cu:555);
+    // density / velocity / curl are outputs of step() in the reference: what is written into them shows until the
+    // next step rewrites them and never reaches the populations -- the same here (lbm_write_field).
     void copy_from_device(const T* device_ptr, size_t size) {
-        if (!m_ctx || size > m_size) return;
-        if (m_field != field::solid || size != m_full) {
-            std::fprintf(stderr, "[error] copy_from_device: only the whole solid mask can be written\n");
-            return;
-        }
-        LBM_CHECK(m_ctx, lbm_set_solid_u8_device(m_ctx, reinterpret_cast<const uint8_t*>(device_ptr), size));
+        if (!m_ctx || size > m_size || size > m_full) return;
+        write(device_ptr, size, 1);
     }
     // cuda_buffer.cuh:56-64: a released buffer answers every later call with a no-op / null.  The fields belong
     // to the solver (external, non-owning memory in the reference's terms, cuda_buffer.cuh:28-29), so nothing is freed.
@@ -96,29 +93,25 @@ class hip_buffer {
     }
     // cuda_buffer.cuh:116: changes the bound the copy calls check against, not the field
     void set_size(const size_t size) { m_size = size; }
-    // cuda_buffer.cuh:72-77 as the solver uses it (lbm_solver.cu:555: the whole solid mask from the
-    // host).  Density / velocity / curl are results of step() here, not inputs: writes to them are
-    // rejected with a log line, where the reference would overwrite values its next step recomputes.
+    // cuda_buffer.cuh:72-77
     void copy_from_host(const T* host_data, size_t size) {
-        if (!m_ctx || size > m_size) return;
-        if (m_field != field::solid || size != m_full) {
-            std::fprintf(stderr, "[error] copy_from_host: only the whole solid mask can be written\n");
-            return;
-        }
-        LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, reinterpret_cast<const uint8_t*>(host_data), size));
+        if (!m_ctx || size > m_size || size > m_full) return;
+        write(host_data, size, 0);
     }
-    // cuda_buffer.cuh:86-91 as the solver uses it (lbm_solver.cu:415: d_solid.memset(0))
+    // cuda_buffer.cuh:66-70: byte-wise fill of the whole array (lbm_solver.cu:415: d_solid.memset(0))
     void memset(int value) {
-        if (!m_ctx) return;
-        if (m_field != field::solid) {
-            std::fprintf(stderr, "[error] memset: only the solid mask can be written\n");
-            return;
-        }
-        std::vector<uint8_t> v(m_full, static_cast<uint8_t>(value));
-        LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, v.data(), v.size()));
+        if (!m_ctx || m_size < m_full) return;
+        std::vector<T> v(m_full);
+        std::memset(static_cast<void*>(v.data()), value, m_full * sizeof(T));
+        write(v.data(), m_full, 0);
     }
-    // device pointer in the reference wire format, up to date and synchronised
-    T* get_data() {
+    // device pointer in the reference wire format, up to date and synchronised (cuda_buffer.cuh:100-114)
+    T* get_data() { return const_cast<T*>(data_ptr()); }
+    [[nodiscard]] const T* get_data() const { return data_ptr(); }
+    size_t size() const { return m_size; }
+
+   private:
+    const T* data_ptr() const {
         if (!m_ctx) {
             std::fprintf(stderr, "[error] Trying to access null device pointer!\n");
             return nullptr;
@@ -129,15 +122,25 @@ class hip_buffer {
         LBM_CHECK(m_ctx, lbm_device_fields(m_ctx, &rho, &u, m_field == field::curl ? &curl : nullptr,
                                            m_field == field::solid ? &solid : nullptr));
         switch (m_field) {
-            case field::density: return reinterpret_cast<T*>(rho);
-            case field::velocity: return reinterpret_cast<T*>(u);
-            case field::curl: return reinterpret_cast<T*>(curl);
-            default: return reinterpret_cast<T*>(solid);
+            case field::density: return reinterpret_cast<const T*>(rho);
+            case field::velocity: return reinterpret_cast<const T*>(u);
+            case field::curl: return reinterpret_cast<const T*>(curl);
+            default: return reinterpret_cast<const T*>(solid);
         }
     }
-    size_t size() const { return m_size; }
-
-   private:
+    void write(const T* src, size_t size, int on_device) {
+        if (m_field == field::solid) {
+            if (size != m_full) {   // the packed mask is rebuilt as a whole
+                std::fprintf(stderr, "[error] solid mask: only the whole mask can be written (%zu of %zu elements given)\n", size, m_full);
+                return;
+            }
+            if (on_device) LBM_CHECK(m_ctx, lbm_set_solid_u8_device(m_ctx, reinterpret_cast<const uint8_t*>(src), size));
+            else LBM_CHECK(m_ctx, lbm_set_solid_u8(m_ctx, reinterpret_cast<const uint8_t*>(src), size));
+            return;
+        }
+        const int which = m_field == field::density ? LBM_FIELD_DENSITY : (m_field == field::velocity ? LBM_FIELD_VELOCITY : LBM_FIELD_CURL);
+        LBM_CHECK(m_ctx, lbm_write_field(m_ctx, which, src, size, on_device));
+    }
     void read_all(T* dst) {
         switch (m_field) {
             case field::density: LBM_CHECK(m_ctx, lbm_read_density(m_ctx, reinterpret_cast<float*>(dst), m_full)); break;
@@ -202,6 +205,11 @@ class lbm_solver {
     hip_buffer<cuda_math::vec4>& get_velocity() { return d_u; }
     hip_buffer<unsigned char>& get_solid_mask() { return d_solid; }
     hip_buffer<float>& get_curl() { return d_curl; }
+    // a `const lbm_solver&` consumer (a renderer that only reads) gets the const views
+    const hip_buffer<float>& get_density() const { return d_rho; }
+    const hip_buffer<cuda_math::vec4>& get_velocity() const { return d_u; }
+    const hip_buffer<unsigned char>& get_solid_mask() const { return d_solid; }
+    const hip_buffer<float>& get_curl() const { return d_curl; }
 
     int get_width() const { return m_width; }
     int get_height() const { return m_height; }

@@ -22,7 +22,7 @@ LAYOUT_ROWS = 2
 TWO_STEP_AUTO = 0
 TWO_STEP_OFF = 1
 
-ABI_VERSION = 2   # include/lbm_abi.h LBM_ABI_VERSION
+ABI_VERSION = 3   # include/lbm_abi.h LBM_ABI_VERSION
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblbm_hip.so")
@@ -64,6 +64,8 @@ SIGNATURES = {
     "lbm_set_solid_u8": ([_ctx, _up, C.c_size_t], C.c_int),
     "lbm_set_solid_u8_device": ([_ctx, C.c_void_p, C.c_size_t], C.c_int),
     "lbm_device_copy": ([_ctx, C.c_void_p, C.c_void_p, C.c_size_t], C.c_int),
+    "lbm_copy_to_host": ([_ctx, C.c_void_p, C.c_void_p, C.c_size_t], C.c_int),
+    "lbm_write_field": ([_ctx, C.c_int, C.c_void_p, C.c_size_t, C.c_int], C.c_int),
     "lbm_load_mesh": ([_ctx, C.c_char_p], C.c_int),
     "lbm_step": ([_ctx, C.c_int], C.c_int),
     "lbm_compute_curl": ([_ctx], C.c_int),
@@ -103,6 +105,7 @@ SIGNATURES = {
     "lbm_pair_interior": ([_ctx], C.c_int),
     "lbm_pair_boundary_second": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_pair_finish": ([_ctx], C.c_int),
+    "lbm_fused_chain_stamps": ([_ctx, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_int)], C.c_int),
 }
 
 _lib = None
@@ -286,6 +289,17 @@ class Solver:
         s = Stats()
         self._chk(self._lib.lbm_get_stats(self._ctx, C.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def fused_chain_stamps(self):
+        """(start, end) device-clock stamps (100 MHz) of every workgroup of one k_fused2 launch, shape (n, 2);
+        None when the two-steps-per-pass path is not in use."""
+        n = C.c_int(0)
+        self._chk(self._lib.lbm_fused_chain_stamps(self._ctx, None, 0, C.byref(n)))
+        if n.value == 0:
+            return None
+        out = np.zeros((n.value, 2), np.uint64)
+        self._chk(self._lib.lbm_fused_chain_stamps(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n)))
+        return out
 
     def timer_begin(self):
         self._chk(self._lib.lbm_timer_begin(self._ctx))

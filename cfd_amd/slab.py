@@ -29,6 +29,33 @@ def slab_range(depth_global, world, rank):
     return z0, base + (1 if rank < rem else 0)
 
 
+def balanced_ranges(depth_global, ranges, times, min_layers=8):
+    """Re-cut the depth into len(ranges) contiguous slabs of equal COST.  `ranges` = [(z0, layers)] of a run whose
+    slabs took `times` per step each (any unit, measured with no waiting on neighbours in it): the cost of a layer
+    is taken as its slab's time / layers, and the new cuts put an equal share of the summed cost into every slab
+    (at least `min_layers` each).  A wind tunnel around an obstacle is not uniform in z: of the eight 64-layer
+    slabs of BASELINE.json configs[3] the two that hold the car's flanks step 20 % slower than the four through
+    its middle (more solid cells: less to update), and the slowest slab sets the step of all.
+    Returns [(z0, layers)]; any partition gives the same fields bit for bit (tests/test_slab_gpu.py)."""
+    P = len(ranges)
+    if P != len(times) or P < 1 or sum(d for _, d in ranges) != depth_global or min_layers * P > depth_global:
+        raise ValueError("balanced_ranges: ranges / times do not describe a partition of the depth")
+    cost = np.zeros(depth_global)
+    for (z0, d), t in zip(ranges, times):
+        cost[z0:z0 + d] = float(t) / d
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for k in range(1, P):
+        z = int(np.searchsorted(cum, cum[-1] * k / P))
+        if z > 0 and abs(cum[z - 1] - cum[-1] * k / P) < abs(cum[z] - cum[-1] * k / P):
+            z -= 1
+        z = max(z, cuts[-1] + min_layers)
+        z = min(z, depth_global - (P - k) * min_layers)
+        cuts.append(z)
+    cuts.append(depth_global)
+    return [(cuts[k], cuts[k + 1] - cuts[k]) for k in range(P)]
+
+
 def neighbours(preset, world, rank):
     """(down, up) ranks or None.  The wind-tunnel preset exchanges around a ring because the
     reference's unchecked outlet index wraps from the last z layer to the first (quirk Q2,
@@ -67,6 +94,21 @@ class HipSlabEngine:
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
+
+    # the two-stream schedule as SlabSolver sees it (CPU engines in the tests answer the same calls with no-ops)
+    @property
+    def has_side(self):
+        return self.bstream is not None
+
+    def side_ctx(self):
+        """launches and transport calls inside run on / are ordered behind the boundary stream"""
+        return torch.cuda.stream(self.bstream)
+
+    def side_wait_main(self):
+        self.bstream.wait_stream(self.stream)
+
+    def main_wait_side(self):
+        self.stream.wait_stream(self.bstream)
 
     def set_streams(self, main, side=None):
         """Rebind the context to other torch streams (see SlabSolver.autotune_streams)."""
@@ -324,8 +366,7 @@ class SlabSolver:
 
     def _step(self, nsteps=1):
         e = self.e
-        main = getattr(e, "stream", None)
-        side = getattr(e, "bstream", None)
+        two = bool(getattr(e, "has_side", False))
         msg_b = self.send[SIDE_BOTTOM] if self.down is not None else None
         msg_t = self.send[SIDE_TOP] if self.up is not None else None
         rcv_b = self.recv[SIDE_BOTTOM] if self.down is not None else None
@@ -333,24 +374,26 @@ class SlabSolver:
         # Two steps per exchange pattern where the engine offers it (HIP A/B slabs on two streams): the fused
         # kernel advances the interior by two steps while the boundary layers take two ordinary steps, each
         # followed by its exchange.  The last step of a batch stays a single split step (rho/u on demand).
+        # A rank decides for itself: a pair sends the same two messages per face, in the same order, as two single
+        # split steps, so neighbours that pair and neighbours that do not step together.
         pairs = 0
-        if nsteps >= 3 and side is not None and self.use_pairs and hasattr(e, "pair_available") and e.pair_available():
+        if nsteps >= 3 and two and self.use_pairs and hasattr(e, "pair_available") and e.pair_available():
             pairs = (nsteps - 1) // 2
         for _ in range(pairs):
-            side.wait_stream(main)                     # previous step's unpack / swap is done
-            with torch.cuda.stream(side):
+            e.side_wait_main()                         # previous step's unpack / swap is done
+            with e.side_ctx():
                 e.pair_boundary_first(msg_b, msg_t)    # boundary layers t -> t+1 + messages, on the side stream
             e.pair_interior()                          # rim t -> t+1, fused interior t -> t+2, rim t+1 -> t+2
-            with torch.cuda.stream(side):
+            with e.side_ctx():
                 self.t.wait(self.t.exchange(self._items(self.send, self.recv)))
                 e.halo_unpack_both(rcv_b, rcv_t)       # neighbours' t+1 layers (the library routes them)
                 e.pair_boundary_second(msg_b, msg_t)   # boundary layers t+1 -> t+2 + messages
                 self.t.wait(self.t.exchange(self._items(self.send, self.recv)))
                 e.halo_unpack_both(rcv_b, rcv_t)       # neighbours' t+2 layers into the new state's ghost layers
-            main.wait_stream(side)
+            e.main_wait_side()
             e.pair_finish()
         for _ in range(nsteps - 2 * pairs):
-            if side is None:
+            if not two:
                 # one stream: boundary layers, then the exchange travels while the interior updates
                 e.step_boundary(msg_b, msg_t)
                 h = self.t.exchange(self._items(self.send, self.recv))
@@ -361,14 +404,14 @@ class SlabSolver:
                 # stream at the same time.  The interior launch is issued BEFORE the RCCL calls:
                 # enqueueing a send/recv group costs the host ~100 us, and the GPU would sit idle
                 # behind the short boundary kernel for that long if the interior came after it.
-                side.wait_stream(main)                 # previous step's unpack / swap is done
-                with torch.cuda.stream(side):
+                e.side_wait_main()                     # previous step's unpack / swap is done
+                with e.side_ctx():
                     e.step_boundary(msg_b, msg_t)      # library launches on the side stream
                 e.step_phase_interior()
-                with torch.cuda.stream(side):
+                with e.side_ctx():
                     h = self.t.exchange(self._items(self.send, self.recv))   # ordered behind the boundary layers only
                     self.t.wait(h)
-                main.wait_stream(side)
+                e.main_wait_side()
             e.halo_unpack_both(rcv_b, rcv_t)
             e.step_finish()
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 2
+#define LBM_ABI_VERSION 3
 #define LBM_Q 19
 
 typedef struct lbm_ctx lbm_ctx;
@@ -148,6 +148,16 @@ int lbm_set_solid_u8_device(lbm_ctx* ctx, const uint8_t* d_mask, size_t n);
  * device and stream, for hosts that do not link the HIP runtime themselves (the source is a pointer obtained
  * from lbm_device_fields). */
 int lbm_device_copy(lbm_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* cuda_buffer<T>::copy_to_host with fewer elements than the field holds -- cuda_buffer.cuh:79-84: a blocking
+ * device-to-host copy of `bytes` from a pointer obtained from lbm_device_fields. */
+int lbm_copy_to_host(lbm_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* cuda_buffer<T>::copy_from_host / copy_from_device / memset on d_rho, d_u (vec4) and d_curl -- cuda_buffer.cuh:66-77,
+ * 86-91.  These arrays are outputs of step() in the reference (lbm_solver.cu:336-337, :655): what a caller writes is
+ * what readers see until the next step rewrites the array, and it never reaches the populations.  Same here: the
+ * first `count` elements of the field (of the current field window for density / velocity) are overwritten, from
+ * host memory or (src_on_device != 0) from device memory; the next lbm_step() supersedes them. */
+enum { LBM_FIELD_DENSITY = 0, LBM_FIELD_VELOCITY = 1, LBM_FIELD_CURL = 2 };
+int lbm_write_field(lbm_ctx* ctx, int field, const void* src, size_t count, int src_on_device);
 /* lbm_solver::load_mesh -- lbm_solver.cu:521-556 + MeshVoxelizer (mesh_voxelizer.cpp:20-246):
  * OBJ -> rotate_y(-90) -> 0.8 auto-scale -> +X ray-cast voxelisation -> y=0 plane solid ->
  * whole mask replaced.  A missing file returns LBM_ERR_IO after installing the floor-only mask,
@@ -178,8 +188,9 @@ int lbm_read_curl(lbm_ctx* ctx, float* curl, size_t n);
  *   lbm_read_speed: |u.xyz| per cell (cuda_math::length, cuda_math.cuh:142-145), n = W*H*nz. */
 int lbm_read_velocity_strided(lbm_ctx* ctx, int sx, int sy, int sz, float* u_xyzw, size_t n);
 int lbm_read_speed(lbm_ctx* ctx, float* speed, size_t n);
-/* lbm_read_velocity_strided for callers that cannot allocate: code under HIP graph capture, a renderer's
- * per-frame loop (hipMalloc / hipFree synchronise the device), harnesses that forbid allocation.  No
+/* lbm_read_velocity_strided for callers that cannot allocate: a renderer's per-frame loop (hipMalloc / hipFree
+ * synchronise the device), serving loops and harnesses that forbid allocation.  It still synchronises the
+ * context's stream and copies to (pageable) host memory, so it is NOT a call for code under HIP graph capture.  No
  * counterpart in the reference.  Same arguments and result; the sampling kernel's staging area is a fixed
  * array inside the library's code object (LBM_NOALLOC_MAX_SAMPLES samples of 4 floats = 4 MiB, held by
  * every GPU the library runs on until the process ends) instead of a hipMalloc per call, and the call
@@ -304,6 +315,14 @@ int lbm_pair_boundary_first(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top)
 int lbm_pair_interior(lbm_ctx* ctx);
 int lbm_pair_boundary_second(lbm_ctx* ctx, float* d_msg_bottom, float* d_msg_top);
 int lbm_pair_finish(lbm_ctx* ctx);
+
+/* Diagnostic of the two-steps-per-pass path (no counterpart in the reference): one k_fused2 launch from the current
+ * state into the other population buffer in which every workgroup records its start and end time (100 MHz
+ * device clock): stamps[2 i], stamps[2 i + 1] for workgroup i; *nworkgroups = workgroups of a launch (0: the fused
+ * path is not in use).  stamps == NULL only asks for the count.  The state does not advance, but rho/u of the
+ * last step can no longer be recomputed on demand until the next lbm_step().  tools/chain_spread.py prints how
+ * evenly the block chains of a launch end. */
+int lbm_fused_chain_stamps(lbm_ctx* ctx, uint64_t* stamps, size_t n, int* nworkgroups);
 
 #ifdef __cplusplus
 }

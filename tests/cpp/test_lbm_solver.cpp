@@ -105,6 +105,61 @@ static void MaskWritesAndSchemes() {
 
 // the rest of cuda_buffer's surface (cuda_buffer.cuh:56-64, 86-98, 116): device-to-device copies out of a field
 // and into the mask, set_size, release.  The "renderer side" device arrays here are other solvers' fields.
+// what a read-only consumer of the solver compiles against (cuda_buffer.cuh:93,108-114: const overloads)
+static void read_only_consumer(const lbm_solver& s, std::vector<float>& rho_prefix, cuda_math::vec4* d_dst, size_t n) {
+    const float* d_rho = s.get_density().get_data();
+    EXPECT(d_rho != nullptr);
+    s.get_velocity().copy_to_device(d_dst, n);
+    EXPECT(s.get_density().size() == n && rho_prefix.size() <= n);
+}
+
+// cuda_buffer<T>::copy_from_host / memset on the OUTPUT arrays (cuda_buffer.cuh:66-77): the reference shows what was
+// written until the next step rewrites the array, and the populations never see it
+static void FieldWritesAndConstViews() {
+    const int W = 72, H = 18, D = 10;
+    const size_t n = static_cast<size_t>(W) * H * D;
+    lbm_solver a(W, H, D), b(W, H, D);
+    a.init(); b.init();
+    a.add_solid({20, 0, 3, 6, 5, 4}); b.add_solid({20, 0, 3, 6, 5, 4});
+    for (int i = 0; i < 4; i++) { a.step(); b.step(); }
+    std::vector<float> seed(n, 2.5f), got(n, 0.0f), rb(n), ra(n);
+    a.get_density().copy_from_host(seed.data(), n);             // a test harness seeding rho
+    a.get_density().copy_to_host(got.data(), n);
+    EXPECT(got == seed);
+    std::vector<float> part(7, -3.0f);
+    a.get_density().copy_from_host(part.data(), 7);             // a prefix
+    a.get_density().copy_to_host(got.data(), 9);                // a prefix back, without a whole-field temporary
+    EXPECT(got[0] == -3.0f && got[6] == -3.0f && got[7] == 2.5f && got[8] == 2.5f);
+    a.get_velocity().memset(0);
+    std::vector<cuda_math::vec4> ua(n), ub(n);
+    a.get_velocity().copy_to_host(ua.data(), n);
+    bool zero = true;
+    for (const auto& v : ua) zero = zero && v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f;
+    EXPECT(zero);
+    a.get_curl().memset(0);                                     // the curl array likewise
+    a.get_curl().copy_to_host(got.data(), n);
+    EXPECT(got[n / 2] == 0.0f);
+    // the next step rewrites all of it: a and b still agree bit for bit
+    a.step(); b.step();
+    a.get_density().copy_to_host(ra.data(), n);
+    b.get_density().copy_to_host(rb.data(), n);
+    EXPECT(ra == rb);
+    a.get_velocity().copy_to_host(ua.data(), n);
+    b.get_velocity().copy_to_host(ub.data(), n);
+    EXPECT(std::memcmp(ua.data(), ub.data(), n * sizeof(cuda_math::vec4)) == 0);
+    // a partial write of the solid mask is refused (the packed mask is rebuilt as a whole), a whole one taken
+    std::vector<unsigned char> m(n, 0), m2(n, 1);
+    a.get_solid_mask().copy_from_host(m.data(), 5);
+    a.get_solid_mask().copy_to_host(m2.data(), n);
+    b.get_solid_mask().copy_to_host(m.data(), n);
+    EXPECT(m == m2);
+    // const views
+    std::vector<float> pre(4);
+    read_only_consumer(a, pre, b.get_velocity().get_data(), n);
+    b.get_velocity().copy_to_host(ub.data(), n);
+    EXPECT(std::memcmp(ua.data(), ub.data(), n * sizeof(cuda_math::vec4)) == 0);
+}
+
 static void DeviceCopiesSetSizeRelease() {
     const int W = 80, H = 20, D = 12;
     const size_t n = static_cast<size_t>(W) * H * D;
@@ -153,6 +208,7 @@ int main(int argc, char** argv) {
     ResetAndStep(argc > 1 ? argv[1] : "tests/golden/cube.obj");
     MaskWritesAndSchemes();
     DeviceCopiesSetSizeRelease();
+    FieldWritesAndConstViews();
     std::printf(failures ? "%d FAILED\n" : "all C++ lbm_solver tests passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -13,8 +13,15 @@ DOWN5 = [6, 12, 13, 16, 17]
 
 
 class OracleSlabEngine:
-    def __init__(self, W, H, depth_global, z0, D, preset):
+    def __init__(self, W, H, depth_global, z0, D, preset, two_streams=False, pairs=False):
+        """two_streams: answer SlabSolver's two-stream schedule (stream calls are no-ops on the CPU).  pairs: offer
+        the lbm_pair_* protocol (include/lbm_abi.h): a pair of steps as two split steps whose interior launches are
+        deferred the way the HIP engine defers them -- the same two messages per face in the same order."""
         self.W, self.H, self.D, self.Dg, self.z0, self.preset = W, H, D, depth_global, z0, preset
+        self.has_side = two_streams
+        self.pairs = pairs
+        self.pair_phase = 0
+        self.log = []
         self.layer = W * H
         self.nl = self.layer * (D + 2)
         w = O.tables()["w"]
@@ -59,6 +66,48 @@ class OracleSlabEngine:
     def step_finish(self):
         self.cur = 1 - self.cur
         self.phase = 0
+        self.log.append("single")
+
+    step_phase_interior = step_interior
+
+    # ---- the two-stream schedule and the pair protocol, as cfd_amd/slab.py SlabSolver drives them ----
+    def side_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def side_wait_main(self):
+        pass
+
+    def main_wait_side(self):
+        pass
+
+    def pair_available(self):
+        return bool(self.pairs) and self.phase == 0 and self.pair_phase == 0
+
+    def pair_boundary_first(self, msg_bottom=None, msg_top=None):
+        assert self.pair_phase == 0 and self.phase == 0
+        self.step_boundary(msg_bottom, msg_top)        # boundary layers t -> t+1, messages
+        self.pair_phase = 1
+
+    def pair_interior(self):
+        assert self.pair_phase == 1
+        self.step_interior()                           # (the HIP engine advances the interior by two steps here)
+        self.pair_phase = 2
+
+    def pair_boundary_second(self, msg_bottom=None, msg_top=None):
+        assert self.pair_phase == 2                    # the first step's messages have been unpacked
+        self.cur = 1 - self.cur
+        self.phase = 0
+        self.step_boundary(msg_bottom, msg_top)        # boundary layers t+1 -> t+2, messages
+        self.pair_phase = 3
+
+    def pair_finish(self):
+        assert self.pair_phase == 3
+        self.step_interior()
+        self.cur = 1 - self.cur
+        self.phase = 0
+        self.pair_phase = 0
+        self.log.append("pair")
 
     def _state(self):
         return self.f[1 - self.cur] if self.phase else self.f[self.cur]

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported(lbm):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/lbm_abi.h but not exported"
     assert sorted(lbm.SIGNATURES) == names
-    assert L.lbm_abi_version() == lbm.ABI_VERSION == 2
+    assert L.lbm_abi_version() == lbm.ABI_VERSION == 3
 
 
 def test_no_silent_cpu_fallback(lbm):

@@ -45,3 +45,20 @@ def test_gpus_1_plain_does_not_launch():
     rec = json.loads(out.strip())
     assert rec.pop("stepped") == rec.pop("agreed_steps")
     assert rec == {"dry_run": True, "n_gpus": 1, "max_over_ranks": 1.0, "gpus_arg": 1}
+
+
+def test_a_dead_rank_ends_the_launcher_with_an_error():
+    """round-2 review: the launcher waited for its ranks without a limit, so one rank that never returns became
+    somebody else's 600 s kill.  With BENCH_LAUNCH_TIMEOUT the launcher kills the ranks' process group itself and
+    exits non-zero; nothing of the group is left running."""
+    import time
+    t0 = time.time()
+    rc, out, err = run_bench("--gpus", "2", "--dry-run-launcher",
+                             env_extra={"BENCH_DRY_RUN_HANG": "1", "BENCH_LAUNCH_TIMEOUT": "25"})
+    assert rc == 124, (rc, err[-2000:])
+    assert time.time() - t0 < 120
+    assert "killing their process group" in err
+    assert out.strip() == ""                          # rank 0 printed, but a failed job relays no result line
+    time.sleep(1.0)
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --dry-run-launcher"], stdout=subprocess.PIPE).stdout.decode().split()
+    assert left == [], left

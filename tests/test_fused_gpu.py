@@ -70,6 +70,28 @@ def test_fused_variants_with_obstacles(oracle, lbm, variant, zsplit, monkeypatch
             assert st["fused_cells"] + st["rim_cells"] <= W * H * D
 
 
+@pytest.mark.parametrize("preset", [0, 1])
+def test_fused_path_takes_a_domain_with_obstacles(oracle, lbm, preset):
+    """a planner that silently declined (or barely used) a domain would still pass every parity test: on the
+    row-interleaved layout at least half of this domain must go through the fused kernel, obstacles inside its
+    blocks included, and equal the oracle"""
+    import os
+    if os.environ.get("LBM_LAYOUT") != str(lbm.LAYOUT_ROWS):
+        pytest.skip("the fused path runs on the row-interleaved layout")
+    W, H, D = 200, 60, 48
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    for s in (o, g):
+        s.init()
+        s.add_solid(60, 0, 16, 30, 20, 14)
+        s.add_solid(130, 30, 8, 10, 9, 30)
+    o.step(7); g.step(7)
+    same(o, g, f"preset {preset}")
+    st = g.stats()
+    assert st["fused_cells"] >= W * H * D // 2, st
+    assert st["rim_cells"] > 0 and st["fused_cells"] + st["rim_cells"] <= W * H * D
+
+
 def test_fused_cube_64(oracle, lbm):
     """BASELINE.json configs[0]: 64^3 channel around assets/cube.obj, 100 steps in calls of mixed length"""
     o = oracle.Solver(64, 64, 64)

@@ -135,11 +135,29 @@ def test_pair_call_order_is_enforced(lbm):
     with pytest.raises(lbm.LbmError):
         e.pair_boundary_second(send[0], send[1])
     e.pair_interior()
+    # round-2 advice: while a pair is in flight nothing but its own calls may touch the state -- the single-side
+    # pack / unpack would write the ghost layers the fused kernel is reading, the mutators the mask and populations
+    for call in (lambda: e.halo_unpack(0, recv[0]), lambda: e.halo_pack(1, send[1]), lambda: e.solver.add_solid(1, 1, 1, 2, 2, 2),
+                 lambda: e.solver.init(), lambda: e.solver.set_solid(np.zeros(136 * 44 * 12, np.uint8)),
+                 lambda: e.solver.set_populations(np.zeros((19, 136 * 44 * 12), np.float32)),
+                 lambda: e.set_mask_ghost(0, np.zeros(136 * 44, np.uint8))):
+        with pytest.raises(lbm.LbmError) as err:
+            call()
+        assert err.value.code == -5
     e.halo_unpack_both(recv[0], recv[1])
     e.pair_boundary_second(send[0], send[1])
     e.halo_unpack_both(recv[0], recv[1])
     e.pair_finish()
     e.solver.step(1)
+    # ... and a split single step likewise keeps the mutators out until lbm_step_finish
+    e.step_boundary(send[0], send[1])
+    with pytest.raises(lbm.LbmError) as err:
+        e.solver.add_solid(1, 1, 1, 2, 2, 2)
+    assert err.value.code == -5
+    e.step_interior()
+    e.halo_pack(0, send[0])                      # (packing the new state before lbm_step_finish is part of the protocol)
+    e.step_finish()
+    e.solver.add_solid(1, 1, 1, 2, 2, 2)
     e.solver.close()
     # an undecomposed context has no pairs of this kind
     g = lbm.Solver(136, 30, 24)

@@ -67,4 +67,18 @@ with open(os.path.join(dst, f"{prefix}_{tag}_pmc_traffic.txt"), "w") as f:
         mean = sum(int(r["Calls"]) * float(r["AverageNs"]) for r in same) / calls
         f.write(f"kernel-trace stats, all {calls} {dominant} launches: average {mean / 1e3:.2f} us\n")
     f.write("bench line of the kernel-trace pass: " + line)
+
+# machine-readable twin for bench.py's `roofline.traffic` / `hbm_frac` (bench.py counter_traffic()): quoted there only
+# while the kernel sources still hash to what this profile was taken on
+sys.path.insert(0, root)
+import bench  # noqa: E402
+dom_stats = [r for r in stats if r["Name"] == vals["FETCH_SIZE"][2]]
+with open(os.path.join(dst, f"{prefix}_{tag}_traffic.json"), "w") as f:
+    json.dump({"kernel": dominant, "kernel_symbol": "%s<%s>" % inst(vals["FETCH_SIZE"][2]), "workload": b["config"]["workload"],
+               "cell_updates_per_launch": b["roofline"]["cell_updates_per_launch"],
+               "fetch_bytes": fetch_b, "write_bytes": write_b, "dispatches": vals["FETCH_SIZE"][1],
+               "launch_us": round(float(dom_stats[0]["AverageNs"]) / 1e3, 2) if dom_stats else None,
+               "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 counts wide streaming reads at half), WRITE_SIZE KiB x1024; separate --pmc passes",
+               "source_hashes": bench.source_hashes()}, f, indent=1)
+    f.write("\n")
 print(open(os.path.join(dst, f"{prefix}_{tag}_pmc_traffic.txt")).read())
