@@ -378,18 +378,15 @@ def run_single(lbm, size, preset_name, scheme_name, obstacle, steps, warmup, min
             if mode == "plain":
                 solver.step(n)
                 return
-            for _ in range(n):                   # the engine's frame loop: one step, then the fields on the device
-                solver.step(1)
-                solver._chk(solver._lib.lbm_device_fields(solver._ctx, C.byref(rho), C.byref(u),
-                                                          C.byref(curl) if mode == "rho_u_curl" else None, None))
+            # the engine's frame loop (one step, rho / u and the curl rewritten by every step: lbm_solver.cu:336-337,488)
+            # kept on the device: lbm_step_frames
+            solver.step_frames(n, curl=mode == "rho_u_curl")
 
         def fence():
             torch.cuda.synchronize()
 
         step(warmup)
         n, dt, dev_ms, st = timed_steps(solver, step, steps, min_seconds, fence)
-        if mode != "plain":
-            dev_ms = dt * 1e3                    # the per-step field passes run outside lbm_step's launches: wall time of the loop
         fluid = fluid_cells(solver, obstacle)
         bpc = {"plain": BYTES_PER_CELL, "rho_u": 172, "rho_u_curl": 192}[mode]
         res = {"cells": W * H * D, "fluid_cells": fluid, "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
@@ -398,11 +395,13 @@ def run_single(lbm, size, preset_name, scheme_name, obstacle, steps, warmup, min
         if mode == "plain":
             res["roofline"] = roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")
         else:
-            ach = fluid * bpc * n / dt / 1e9
+            ach = fluid * bpc * n / (dev_ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "hbm_frac": None,
                                "kernel": "k_stream_collide (rho/u fused)" + (" + k_curl" if mode == "rho_u_curl" else ""),
-                               "note": "whole frame loop (wall clock): one step per call, fields left on the device"}
+                               "frame_ms": round(dev_ms / n, 5),
+                               "note": "lbm_step_frames: the frames of the timed region back to back on the device, HIP events around the "
+                                       "region on the solver's stream; bytes per cell and frame as SURVEY.md 8d prices this output mode"}
         return res
     finally:
         solver.close()

@@ -75,13 +75,21 @@ __device__ __forceinline__ int f2_role(int wave) {   // 0 .. TY+1: row of the ha
 // first step, one direction: k_stream_collide's interior gather (gather_fast) as base + 32-bit offset.
 // `base` = start of the chunk's lowest input layer; `off` / `offm` = byte offset of the lane's cell from it
 // (offm: one float to the left for the outlet lane x = W-1, whose cx = -1 directions copy from x = W-1).
+// The x shift (-cx floats) is NOT part of the address: the caller applies it as the instruction's immediate offset
+// (F2_XOFF<K> bytes), so that the scalar base + 32-bit lane offset form of the load survives (the compiler otherwise
+// builds 64-bit lane addresses for the ten x-shifted directions: two v_lshl_add_u64 each per layer).
+#ifndef F2_OPT
+#define F2_OPT 8    // measured at 256^3 and 512x256x256 + car (profiles/r03_tuning.md): only bit 3 is worth having. bit 0: x shift as immediate offset, 1: unconditional exchange reads, 2: scalar store bases, 3: per-iteration M0 / plane stride
+#endif
+template <int K>
+constexpr int F2_XOFF = (F2_OPT & 1) ? -CX[K] * 4 : 0;
 template <int PRESET, int K>
 __device__ __forceinline__ const float* f2_src(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
                                                bool xl, bool xr, bool bb) {
     constexpr int cx = CX[K];
-    const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row - cx) * 4;
-    // bounce-back (a cavity wall, or with OBST a solid neighbour): the own cell's opposite population
-    const long long dw = (long long)INV[K] * g.plane * 4;
+    const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row) * 4 - (cx * 4 + F2_XOFF<K>);
+    // bounce-back (a cavity wall, or with OBST a solid neighbour): the own cell's opposite population, no x shift
+    const long long dw = (long long)INV[K] * g.plane * 4 - F2_XOFF<K>;
     const unsigned delta = (unsigned)(int)(dw - dk);              // exact in 32 bits: |dw - dk| < 2 layers (checked on the host)
     if (cx == 0) return reinterpret_cast<const float*>(base + dk + (bb ? off + delta : off));
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF)
@@ -132,17 +140,19 @@ __device__ __forceinline__ bool f2_bb(unsigned nb, bool xr) {
 template <int PRESET, int K>
 struct F2 {
     // issue the first-step loads of one layer into the wave's staging area (LDS-DMA)
+    // (`stage`: LDS byte address of the wave's staging area)
     static __device__ __forceinline__ void issue(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                                 bool xl, bool xr, unsigned nb, float* stage) {
+                                                 bool xl, bool xr, unsigned nb, unsigned stage) {
         F2<PRESET, K - 1>::issue(base, g, off, offm, xl, xr, nb, stage);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)),
-                                         (__attribute__((address_space(3))) void*)(stage + K * 64), 4, 0, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
+                                         // (the instruction's immediate offset moves the LDS address as well: taken off M0 again)
+                                         (__attribute__((address_space(3))) void*)(size_t)(stage + K * 256u - F2_XOFF<K>), 4, F2_XOFF<K>, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
     }
     // the same loads straight into registers (no prefetch)
     static __device__ __forceinline__ void load(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
                                                 bool xl, bool xr, unsigned nb, float* f) {
         F2<PRESET, K - 1>::load(base, g, off, offm, xl, xr, nb, f);
-        f[K] = ldk<1, K>(f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)));
+        f[K] = ldk<1, K>(f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)) + F2_XOFF<K> / 4);
     }
     // staged values -> registers; the inlet lane's cx = +1 directions are the constant inlet equilibrium
     static __device__ __forceinline__ void unstage(const float* stage, int lane, bool xl, float inlet_e, float* f) {
@@ -174,10 +184,14 @@ struct F2 {
             const float v = K == 0 ? cur[0] : (K == 5 ? below[5] : above[6]);
             f[K] = (K != 0 && bb) ? cur[INV[K]] : v;
         } else if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
-            const float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + (cx == -1 ? slotm : slot)];
+            float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + (cx == -1 ? slotm : slot)];
+            // (read by every lane: left to itself the compiler masks the inlet lane out of the read, which costs
+            // three scalar instructions and a move per direction where a select costs one)
+            if (F2_OPT & 2) asm volatile("" : "+v"(v));
             f[K] = (cx == 1 && xl) ? weight(K) * inlet_e : (bb ? cur[INV[K]] : v);
         } else {
-            const float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + slot];
+            float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + slot];
+            if (F2_OPT & 2) asm volatile("" : "+v"(v));
             const bool wall = cx == 1 ? xl : (cx == -1 ? xr : false);
             f[K] = (wall || bb) ? cur[INV[K]] : v;    // wall bounce-back likewise
         }
@@ -185,7 +199,7 @@ struct F2 {
 };
 template <int PRESET>
 struct F2<PRESET, -1> {
-    static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*) {}
+    static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, unsigned) {}
     static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*) {}
     static __device__ __forceinline__ void unstage(const float*, int, bool, float, float*) {}
     static __device__ __forceinline__ void fix_inlet(bool, float, float*) {}
@@ -256,6 +270,10 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     const int slotm = slot - (xr ? 1 : 0);                       // outlet lane: its cx = -1 directions copy from its own column
     const float inlet_e = inlet_bracket(p.U);
     float* stage = lds + NBUF * EXCH + wave * (Q * 64);
+    // the staging area's LDS byte address for the LDS-DMA loads (M0).  Inside the layer loop it passes through an empty
+    // asm, like the plane stride of the stores: derived per iteration by scalar adds, the 19 M0 values and 19 store
+    // bases do not occupy 57 scalar registers across the loop (there are none to spare: they spilled into vector lanes)
+    unsigned stage_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)stage;
 
     // input addressing: byte offsets from layer zs - 3 (two layers of slack keep every offset, the wall and
     // outlet adjustments included, non-negative)
@@ -281,11 +299,13 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     if (STAGE) {
         const unsigned off = off_of(zs - 1);
         if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
-            F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage);
+            F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage_lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     int buf = 0;
+    unsigned plane_s = plane_b;
     for (int L = zs - 1; L <= ze; L++) {
+        if (F2_OPT & 8) asm volatile("" : "+s"(stage_lds), "+s"(plane_s));
         // ---- first step of layer L ---------------------------------------------------------------------
         // (OBST: a wave whose cells of this layer are all solid neither loads nor collides: wave-uniform)
         if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
@@ -303,8 +323,8 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
             if (active && L < ze && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
                 const unsigned off = off_of(L + 1);
                 // (most waves have no solid cell in reach: they take the plain form of the loads, wave-uniformly)
-                if (!OBST || __ballot(nb_next != 0u) == 0ull) F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, 0u, stage);
-                else F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage);
+                if (!OBST || __ballot(nb_next != 0u) == 0ull) F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, 0u, stage_lds);
+                else F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage_lds);
             }
         }
         const unsigned nb_next2 = L + 2 <= ze ? nb_of(L + 2) : 0u;
@@ -323,11 +343,16 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
                 // the staged loads have had the whole second step to land; waiting for them HERE keeps the
                 // latency of the stores below out of the next iteration (stores count in vmcnt too)
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // a scalar base per population (layer and plane offsets: scalar adds) + the lane's constant 32-bit
+                // cell offset: no vector instruction spent on store addresses
+                char* out_layer = base_out + (size_t)((unsigned)(L - 1 - (zs - 3)) * layer_b);
                 const unsigned offo = off_of(L - 1);
                 if (!OBST || !(nb_cur & 1u)) {
 #pragma unroll
-                    for (int k = 0; k < Q; k++)   // one base, 32-bit offsets: population k sits k planes further on
-                        __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (offo + (unsigned)k * plane_b)));
+                    for (int k = 0; k < Q; k++) {
+                        if (F2_OPT & 4) __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(out_layer + (size_t)((unsigned)k * plane_s) + cell_b));
+                        else __builtin_nontemporal_store(o[k], reinterpret_cast<float*>(base_out + (offo + (unsigned)k * plane_b)));
+                    }
                 }
             } else {
                 if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1494,6 +1494,47 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     return LBM_OK;
 }
 
+// The reference's frame loop on the device: every step() writes rho and u (lbm_solver.cu:336-337) and runs the curl pass
+// (:488 -> :612-661).  `nframes` such steps back to back on the context's stream with no host round trip between
+// them; afterwards rho / u (and curl with want_curl) are those of the last frame, exactly as after nframes calls of
+// the reference's step().  172 B per cell and frame, 192 B with the curl pass.
+int lbm_step_frames(lbm_ctx* c, int nframes, int want_curl) {
+    NEED(c);
+    if (nframes < 0) return fail(c, LBM_ERR_INVALID, "lbm_step_frames: nframes %d", nframes);
+    if (nframes == 0) return LBM_OK;
+    if (c->split_phase != 0 || c->pair_phase != 0) return fail(c, LBM_ERR_STATE, "lbm_step_frames: a split step is in flight");
+    if (c->g.fnz == 0) return fail(c, LBM_ERR_STATE, "lbm_step_frames: the field window is empty (lbm_set_field_window)");
+    if (want_curl && c->g.fnz != c->g.D)
+        return fail(c, LBM_ERR_STATE, "lbm_step_frames: the curl's z differences need the whole domain in the field window");
+    int rc = refresh_mask_state(c);
+    if (!rc) rc = ensure_field_buffers(c);
+    if (rc) return rc;
+    if (want_curl && !c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
+    const dim3 cgrid((c->g.W + 63) / 64, (c->g.H + 3) / 4, (c->g.D + CURL_ZCHUNK - 1) / CURL_ZCHUNK);
+    for (int s = 0; s < nframes && !rc; s++) {
+        if (c->scheme == LBM_SCHEME_AA) rc = launch_aa_step(c, 1);
+        else if (c->scheme == LBM_SCHEME_SLIDE) rc = slide_step(c, 1);
+        else {
+            rc = launch_ab_layers(c, 1, c->g.D, 1);
+            c->cur = 1 - c->cur;
+            c->zrev ^= 1;
+        }
+        if (!rc && want_curl) {
+            hipLaunchKernelGGL(k_curl, cgrid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    if (rc) return rc;
+    c->p_last = c->p;
+    c->steps += (uint64_t)nframes;
+    c->fields = FIELDS_VALID;
+    c->prev_touched = false;
+    c->pair_last = false;
+    c->fields_wanted = true;     // this caller reads the fields every frame
+    c->curl_valid = want_curl != 0;
+    return LBM_OK;
+}
+
 int lbm_compute_curl(lbm_ctx* c) {
     NEED(c);
     int rc = refresh_mask_state(c);
@@ -1504,7 +1545,7 @@ int lbm_compute_curl(lbm_ctx* c) {
     if (c->g.fnz != c->g.D)
         return fail(c, LBM_ERR_STATE, "lbm_compute_curl: the curl's z differences need the whole domain in the field window");
     if (!c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
-    dim3 grid((c->g.W + 255) / 256, c->g.H, c->g.D);
+    dim3 grid((c->g.W + 63) / 64, (c->g.H + 3) / 4, (c->g.D + CURL_ZCHUNK - 1) / CURL_ZCHUNK);
     hipLaunchKernelGGL(k_curl, grid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
     HIPCHK(c, hipGetLastError());
     c->curl_valid = true;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lbm_load_mesh": ([_ctx, C.c_char_p], C.c_int),
     "lbm_step": ([_ctx, C.c_int], C.c_int),
     "lbm_compute_curl": ([_ctx], C.c_int),
+    "lbm_step_frames": ([_ctx, C.c_int, C.c_int], C.c_int),
     "lbm_sync": ([_ctx], C.c_int),
     "lbm_set_streams": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_set_field_window": ([_ctx, C.c_int, C.c_int], C.c_int),
@@ -216,6 +217,10 @@ class Solver:
 
     def step(self, nsteps=1):
         self._chk(self._lib.lbm_step(self._ctx, nsteps))
+
+    def step_frames(self, nframes=1, curl=False):
+        """the reference's frame loop on the device: every step writes rho / u (and curl) as lbm_solver::step does"""
+        self._chk(self._lib.lbm_step_frames(self._ctx, nframes, 1 if curl else 0))
 
     def compute_curl(self):
         self._chk(self._lib.lbm_compute_curl(self._ctx))

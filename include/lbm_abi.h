@@ -168,6 +168,12 @@ int lbm_load_mesh(lbm_ctx* ctx, const char* obj_path);
  * swap.  rho/u/curl are not rewritten every step; they are materialised, bit-identical to what
  * the reference's per-step writes would hold, when read (lbm_read_*, lbm_device_fields). */
 int lbm_step(lbm_ctx* ctx, int nsteps);
+/* The reference's frame loop kept on the device -- lbm_solver::step as the engine calls it once per frame
+ * (Engine/src/main.cpp:36): every step rewrites rho and u (lbm_solver.cu:336-337) and runs the curl pass (:488).
+ * `nframes` such steps back to back on the context's stream, no host round trip between them; afterwards rho, u
+ * (and curl if want_curl != 0) are those of the last frame, bit for bit what nframes x { lbm_step(ctx, 1);
+ * lbm_device_fields(...) } leaves.  172 B per cell and frame, 192 B with the curl. */
+int lbm_step_frames(lbm_ctx* ctx, int nframes, int want_curl);
 /* lbm_solver::compute_curl -- lbm_solver.cu:612-661 */
 int lbm_compute_curl(lbm_ctx* ctx);
 /* cudaDeviceSynchronize of the debug build / renderer -- lbm_solver.cu:491-493 */

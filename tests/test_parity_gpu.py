@@ -86,6 +86,39 @@ def test_ragged_domains(oracle, lbm, dims, preset):
     np.testing.assert_array_equal(g.classification(), co)
 
 
+@pytest.mark.parametrize("dims", [(70, 33, 37), (130, 6, 3), (64, 4, 32), (5, 1, 1), (200, 9, 65)])
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_frame_loop_on_the_device(oracle, lbm, dims, scheme):
+    """lbm_step_frames: the reference's per-frame step (rho / u rewritten by every step, then the curl pass:
+    lbm_solver.cu:336-337, 488, 612-661) for n frames without a host round trip equals n single frames and the
+    oracle bit for bit; the curl kernel marches in z over ragged rows, row groups and layer chunks."""
+    W, H, D = dims
+    o = oracle.Solver(W, H, D)
+    g = lbm.Solver(W, H, D, scheme=scheme)
+    h = lbm.Solver(W, H, D, scheme=scheme)
+    for s in (o, g, h):
+        s.init()
+        s.add_solid(W // 3, 0, D // 4, max(1, W // 5), max(1, H // 2), max(1, D // 2))
+    for n in (1, 4):
+        o.step(n)
+        g.step_frames(n, curl=True)
+        for _ in range(n):
+            h.step(1)
+            h.curl_field()
+        # (in place, AA keeps bounce-back values in the solid neighbours' slots: its solid cells are not frozen copies)
+        assert_same_state(o, g, check_f=scheme != 1, what=f"{n} frames")
+        fluid = o.solid_mask() == 0
+        np.testing.assert_array_equal(g.populations()[:, fluid], o.populations()[:, fluid])
+        o.compute_curl()
+        np.testing.assert_array_equal(g.curl_field(), o.curl_field())
+        np.testing.assert_array_equal(g.curl_field(), h.curl_field())
+        np.testing.assert_array_equal(g.populations()[:, fluid], h.populations()[:, fluid])
+    g.step_frames(3)                                  # without the curl pass: the curl of the new state is made on demand
+    o.step(3); o.compute_curl()
+    np.testing.assert_array_equal(g.curl_field(), o.curl_field())
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+
+
 def test_classification_and_mask_bit_exact(oracle, lbm):
     o, g = both(oracle, lbm, 64, 64, 64)
     o.load_mesh(CUBE_OBJ); g.load_mesh(CUBE_OBJ)
