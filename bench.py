@@ -447,7 +447,8 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
         if scheme != lbm.SCHEME_AB:
             # the in-place schemes write rho/u of the field window in every split step: keep it small
             solver.set_field_window(0, min(4, D))
-        drv = slab.SlabSolver(eng, preset, world, rank, slab.TorchP2P())
+        staged = world > 1 and dist.get_backend() == "gloo"
+        drv = slab.SlabSolver(eng, preset, world, rank, slab.HostStagedP2P() if staged else slab.TorchP2P())
         try:
             solver.init()
             if preset == lbm.PRESET_CAVITY:
@@ -585,6 +586,11 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # BENCH_BACKEND=gloo: a rehearsal of the N > 1 code path on fewer GPUs than ranks (ranks share devices, halo
+    # messages staged through the host: cfd_amd/slab.py HostStagedP2P).  Its timings mean nothing; the default is RCCL.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     size, preset_name, scheme_name, obstacle, scaling = CONFIGS[args.config]
     if args.size:
@@ -608,6 +614,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -659,6 +667,8 @@ def main():
             "mlups_per_gpu": round(head["mlups"] / world, 1), "state_finite": head["state_finite"],
             "roofline": head["roofline"],
         }
+        if backend == "gloo":
+            out["rehearsal"] = "BENCH_BACKEND=gloo: ranks may share GPUs, messages staged through the host; not a measurement"
         if slab_path:
             out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "slab_layers", "slab_z0", "slab_ranges", "even_split", "per_rank_ms_no_exchange", "halo_bytes_per_step_per_gpu",
                                                      "ms_per_step_no_exchange", "exposed_comm_ms_per_step") if k in head}

@@ -271,6 +271,31 @@ class TorchP2P:
             w.wait()
 
 
+class HostStagedP2P(TorchP2P):
+    """TorchP2P with every message staged through host memory: for process groups whose backend cannot take device
+    tensors (gloo).  Lets several ranks that SHARE one GPU run the N > 1 code path of bench.py and the tests -- RCCL
+    refuses two ranks on one device.  A rehearsal transport: it synchronises the stream it is called on."""
+
+    def exchange(self, items):
+        torch.cuda.current_stream().synchronize()      # the pack kernels that filled the messages
+        host, back = [], []
+        for send, dst, recv, src in items:
+            hs = send.cpu() if dst is not None else None
+            hr = torch.empty(recv.shape, dtype=recv.dtype) if src is not None else None
+            host.append((hs, dst, hr, src))
+            if hr is not None:
+                back.append((hr, recv))
+        return super().exchange(host), back
+
+    @staticmethod
+    def wait(handle):
+        works, back = handle
+        for w in works:
+            w.wait()
+        for hr, recv in back:
+            recv.copy_(hr)                             # on the current stream, ahead of the unpack kernels
+
+
 class SlabSolver:
     """One rank's share of a W x H x depth_global domain.  Mirrors lbm_solver's surface for the
     calls that make sense per slab (init, step, set_solid with the slab's own layers, read-back)."""
