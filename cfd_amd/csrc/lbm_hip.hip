@@ -139,7 +139,7 @@ struct lbm_ctx {
     // a PAIR of steps on a z-slab (lbm_pair_*): 0 idle, 1 boundary layers of the first step issued, 2 interior issued,
     // 3 boundary layers of the second step issued
     int pair_phase = 0;
-    bool pair_rim_stream = true;   // LBM_PAIR_RIM_STREAM=0: the rim's launches of a pair stay on the context's stream
+    bool pair_rim_stream = false;  // LBM_PAIR_RIM_STREAM=1: the rim's launches of a pair go to a third stream (measured: no gain)
     bool side_prio = true;         // LBM_SIDE_PRIO=0: the short kernels beside k_fused2 do not raise their waves' priority
     hipEvent_t ev_pair_b1 = nullptr, ev_pair_r1 = nullptr;
     bool pair_last = false;        // the last update was a pair: the previous buffer is TWO steps old (no rho/u on demand)
@@ -1494,6 +1494,19 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     return LBM_OK;
 }
 
+int launch_curl(lbm_ctx* c) {
+    // layers per workgroup: as many as leave two workgroups for every CU (the chunk's two end layers are read twice)
+    const int gx = (c->g.W + 63) / 64, gy = (c->g.H + CURL_NW * CURL_R - 1) / (CURL_NW * CURL_R);
+    int zchunk = 64;
+    while (zchunk > 8 && gx * gy * ((c->g.D + zchunk - 1) / zchunk) < 512) zchunk /= 2;   // (256 CUs)
+    if (c->probe) { const char* t = getenv("LBM_CURL_ZCHUNK"); if (t && atoi(t) > 0) zchunk = atoi(t); }
+    const int gz = (c->g.D + zchunk - 1) / zchunk;
+    hipLaunchKernelGGL((k_curl<CURL_NW, CURL_R, CURL_U>), dim3(gx * gy * gz), dim3(CURL_NW * 64), 0, c->stream,
+                       c->u, c->curl, c->g.W, c->g.H, c->g.D, zchunk);
+    HIPCHK(c, hipGetLastError());
+    return LBM_OK;
+}
+
 // The reference's frame loop on the device: every step() writes rho and u (lbm_solver.cu:336-337) and runs the curl pass
 // (:488 -> :612-661).  `nframes` such steps back to back on the context's stream with no host round trip between
 // them; afterwards rho / u (and curl with want_curl) are those of the last frame, exactly as after nframes calls of
@@ -1510,7 +1523,6 @@ int lbm_step_frames(lbm_ctx* c, int nframes, int want_curl) {
     if (!rc) rc = ensure_field_buffers(c);
     if (rc) return rc;
     if (want_curl && !c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
-    const dim3 cgrid((c->g.W + 63) / 64, (c->g.H + 3) / 4, (c->g.D + CURL_ZCHUNK - 1) / CURL_ZCHUNK);
     for (int s = 0; s < nframes && !rc; s++) {
         if (c->scheme == LBM_SCHEME_AA) rc = launch_aa_step(c, 1);
         else if (c->scheme == LBM_SCHEME_SLIDE) rc = slide_step(c, 1);
@@ -1520,8 +1532,8 @@ int lbm_step_frames(lbm_ctx* c, int nframes, int want_curl) {
             c->zrev ^= 1;
         }
         if (!rc && want_curl) {
-            hipLaunchKernelGGL(k_curl, cgrid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
-            HIPCHK(c, hipGetLastError());
+            rc = launch_curl(c);
+            if (rc) return rc;
         }
     }
     if (rc) return rc;
@@ -1545,9 +1557,8 @@ int lbm_compute_curl(lbm_ctx* c) {
     if (c->g.fnz != c->g.D)
         return fail(c, LBM_ERR_STATE, "lbm_compute_curl: the curl's z differences need the whole domain in the field window");
     if (!c->curl) HIPCHK(c, hipMalloc(&c->curl, cells(c) * sizeof(float)));
-    dim3 grid((c->g.W + 63) / 64, (c->g.H + 3) / 4, (c->g.D + CURL_ZCHUNK - 1) / CURL_ZCHUNK);
-    hipLaunchKernelGGL(k_curl, grid, dim3(256), 0, c->stream, c->u, c->curl, c->g.W, c->g.H, c->g.D);
-    HIPCHK(c, hipGetLastError());
+    rc = launch_curl(c);
+    if (rc) return rc;
     c->curl_valid = true;
     return LBM_OK;
 }
@@ -2189,9 +2200,9 @@ int lbm_pair_interior(lbm_ctx* c) {
     hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
     const float* in = c->f[c->cur];
     float* out = c->f[1 - c->cur];
-    // The rim's two steps touch no cell the fused kernel touches.  With a boundary stream in use they go to a third,
-    // library-owned stream beside the fused kernel (LBM_PAIR_RIM_STREAM=0: in front of and behind it on the context's
-    // stream, as round 2 had it: 160 us of a 1.43 ms pair at 1024 x 512 x 64, launch gaps included).
+    // The rim's two steps touch no cell the fused kernel touches: they run in front of and behind it on the context's
+    // stream.  LBM_PAIR_RIM_STREAM=1 sends them to a third, library-owned stream beside the fused kernel instead
+    // (measured at 1024 x 512 x 64: the fused kernel slows by what the rim takes, profiles/r03_tuning.md section 1).
     hipStream_t rs = c->stream;
     if (c->pair_rim_stream && bs != c->stream) {
         if (!c->stream_rim) {
