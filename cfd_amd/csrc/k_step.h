@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     // (w_k), so they need not travel with the lattice: solid lanes neither load nor store (but for the
     // outlet column, which a slab's outlet branch reads from the lattice) and all-solid tiles exit
     const bool skip_solid = MODE == 3 && (want_moments & 2);
+    // want_moments bit 2 (MODE 0): nobody reads rho / u before the next step rewrites them (lbm_step_frames without the
+    // curl pass): store them past the caches like the populations (256^3: 487 -> 480 us per frame; with a reader right
+    // behind -- the curl pass -- the plain store is the faster one, 557 against 560 us)
+    const bool nt_fields = MODE == 0 && (want_moments & 4);
     if (MODE == 0 || MODE == 3) want_moments = (want_moments & 1) && (unsigned)(zl - 1 - g.fz0) < (unsigned)g.fnz;
     if ((MODE == 0 || MODE == 4) && flag == 2 && !want_moments) return;  // every cell of the tile is solid: nothing moves
     if (MODE == 3 && skip_solid && flag == 2 && !want_moments && t.xs != g.Wt - 1 &&
@@ -422,8 +426,14 @@ __global__ __launch_bounds__(256) void k_stream_collide(
     const Moments m = moments_of(f);
     if (MODE == 1 || ((MODE == 0 || MODE == 3) && want_moments)) {
         const long long ridx = ((long long)(zl - 1 - g.fz0) * g.H + y) * g.W + x;
-        rho_out[ridx] = m.rho;
-        u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
+        if (nt_fields) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(m.rho, rho_out + ridx);
+            __builtin_nontemporal_store((v4f){m.ux, m.uy, m.uz, 0.0f}, (v4f*)(u_out + ridx));
+        } else {
+            rho_out[ridx] = m.rho;
+            u_out[ridx] = make_float4(m.ux, m.uy, m.uz, 0.0f);
+        }
         if (MODE == 1) return;
     }
     float o[Q];

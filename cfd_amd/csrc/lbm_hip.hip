@@ -1527,7 +1527,7 @@ int lbm_step_frames(lbm_ctx* c, int nframes, int want_curl) {
         if (c->scheme == LBM_SCHEME_AA) rc = launch_aa_step(c, 1);
         else if (c->scheme == LBM_SCHEME_SLIDE) rc = slide_step(c, 1);
         else {
-            rc = launch_ab_layers(c, 1, c->g.D, 1);
+            rc = launch_ab_layers(c, 1, c->g.D, want_curl ? 1 : 5);
             c->cur = 1 - c->cur;
             c->zrev ^= 1;
         }
