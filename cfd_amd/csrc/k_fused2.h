@@ -83,14 +83,45 @@ __device__ __forceinline__ int f2_role(int wave) {   // 0 .. TY+1: row of the ha
 #endif
 template <int K>
 constexpr int F2_XOFF = (F2_OPT & 1) ? -CX[K] * 4 : 0;
+// Walls (WALL form of the kernel): which of the domain's y / z walls the lane's cell of the current layer lies on.
+// A direction that would pull across one takes a population of the own cell instead, like a solid neighbour's
+// bounce-back, and the solid-neighbour word carries its bit; only the plane differs (lbm_solver.cu:298-312: floor
+// bounce-back, ceiling reflect_y, side reflect_z, tested in that order before any solid; the cavity bounces back
+// from every wall and its lid adds the lid term).
+struct F2Wall {
+    bool bot, top, zlo, zhi;
+};
+constexpr unsigned f2_dirs(int cy_sel, int cz_sel) {   // bit k: CY[k] == cy_sel (cz_sel == 2) or CZ[k] == cz_sel (cy_sel == 2)
+    unsigned m = 0;
+    for (int k = 0; k < Q; k++)
+        if ((cz_sel == 2 && CY[k] == cy_sel) || (cy_sel == 2 && CZ[k] == cz_sel)) m |= 1u << k;
+    return m;
+}
+constexpr unsigned F2_CY_POS = f2_dirs(1, 2), F2_CY_NEG = f2_dirs(-1, 2), F2_CZ_POS = f2_dirs(2, 1), F2_CZ_NEG = f2_dirs(2, -1);
+// the own cell's population that direction K takes when it does not pull (0: INV, 1: RFY, 2: RFZ)
 template <int PRESET, int K>
+__device__ __forceinline__ int f2_own_kind(const F2Wall& w) {
+    if (PRESET != LBM_PRESET_WIND_TUNNEL_REF) return 0;
+    if (CY[K] == 1 && w.bot) return 0;
+    if (CY[K] == -1 && w.top) return 1;
+    if ((CZ[K] == 1 && w.zlo) || (CZ[K] == -1 && w.zhi)) return 2;
+    return 0;
+}
+
+template <int PRESET, int K, int WALL>
 __device__ __forceinline__ const float* f2_src(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                               bool xl, bool xr, bool bb) {
+                                               bool xl, bool xr, bool bb, const F2Wall& w) {
     constexpr int cx = CX[K];
     const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row) * 4 - (cx * 4 + F2_XOFF<K>);
     // bounce-back (a cavity wall, or with OBST a solid neighbour): the own cell's opposite population, no x shift
     const long long dw = (long long)INV[K] * g.plane * 4 - F2_XOFF<K>;
-    const unsigned delta = (unsigned)(int)(dw - dk);              // exact in 32 bits: |dw - dk| < 2 layers (checked on the host)
+    unsigned delta = (unsigned)(int)(dw - dk);                    // exact in 32 bits: |dw - dk| < 2 layers (checked on the host)
+    if (WALL && PRESET == LBM_PRESET_WIND_TUNNEL_REF && (CY[K] == -1 || CZ[K] != 0)) {
+        const int kind = f2_own_kind<PRESET, K>(w);
+        const unsigned dy = (unsigned)(int)((long long)RFY[K] * g.plane * 4 - F2_XOFF<K> - dk);
+        const unsigned dz = (unsigned)(int)((long long)RFZ[K] * g.plane * 4 - F2_XOFF<K> - dk);
+        delta = kind == 1 ? dy : (kind == 2 ? dz : delta);
+    }
     if (cx == 0) return reinterpret_cast<const float*>(base + dk + (bb ? off + delta : off));
     if (PRESET == LBM_PRESET_WIND_TUNNEL_REF)
         return reinterpret_cast<const float*>(base + dk + (bb ? off + delta : (cx == -1 ? offm : off)));
@@ -141,18 +172,20 @@ template <int PRESET, int K>
 struct F2 {
     // issue the first-step loads of one layer into the wave's staging area (LDS-DMA)
     // (`stage`: LDS byte address of the wave's staging area)
+    template <int WALL>
     static __device__ __forceinline__ void issue(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                                 bool xl, bool xr, unsigned nb, unsigned stage) {
-        F2<PRESET, K - 1>::issue(base, g, off, offm, xl, xr, nb, stage);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)),
+                                                 bool xl, bool xr, unsigned nb, unsigned stage, const F2Wall& w) {
+        F2<PRESET, K - 1>::template issue<WALL>(base, g, off, offm, xl, xr, nb, stage, w);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)f2_src<PRESET, K, WALL>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr), w),
                                          // (the instruction's immediate offset moves the LDS address as well: taken off M0 again)
                                          (__attribute__((address_space(3))) void*)(size_t)(stage + K * 256u - F2_XOFF<K>), 4, F2_XOFF<K>, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
     }
     // the same loads straight into registers (no prefetch)
+    template <int WALL>
     static __device__ __forceinline__ void load(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
-                                                bool xl, bool xr, unsigned nb, float* f) {
-        F2<PRESET, K - 1>::load(base, g, off, offm, xl, xr, nb, f);
-        f[K] = ldk<1, K>(f2_src<PRESET, K>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr)) + F2_XOFF<K> / 4);
+                                                bool xl, bool xr, unsigned nb, float* f, const F2Wall& w) {
+        F2<PRESET, K - 1>::template load<WALL>(base, g, off, offm, xl, xr, nb, f, w);
+        f[K] = ldk<1, K>(f2_src<PRESET, K, WALL>(base, g, off, offm, xl, xr, f2_bb<K>(nb, xr), w) + F2_XOFF<K> / 4);
     }
     // staged values -> registers; the inlet lane's cx = +1 directions are the constant inlet equilibrium
     static __device__ __forceinline__ void unstage(const float* stage, int lane, bool xl, float inlet_e, float* f) {
@@ -162,6 +195,12 @@ struct F2 {
     static __device__ __forceinline__ void fix_inlet(bool xl, float inlet_e, float* f) {
         F2<PRESET, K - 1>::fix_inlet(xl, inlet_e, f);
         if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == 1) f[K] = xl ? weight(K) * inlet_e : f[K];
+    }
+    // the cavity's lid row: the bounced-back population gains the lid term (lbm_solver.cu's moving-wall branch as
+    // k_stream_collide's SRC_LID_BB has it: v + lid_term, for every direction that points down from the lid)
+    static __device__ __forceinline__ void fix_lid(bool top, float U, float* f) {
+        F2<PRESET, K - 1>::fix_lid(top, U, f);
+        if (PRESET == LBM_PRESET_CAVITY && CY[K] == -1) f[K] = top ? f[K] + lid_term(K, U) : f[K];
     }
     // what the neighbours need of this cell for the second step of layer z: up-going values of layer z-1,
     // in-plane values of layer z, down-going values of layer z+1
@@ -173,39 +212,46 @@ struct F2 {
     }
     // second step, one direction: the streamed population of cell (col, r) of the tile, with the x ends of
     // the domain handled as in the first step (slotm: the outlet lane reads its own column)
-    template <int PLANE>
+    template <int PLANE, int WALL>
     static __device__ __forceinline__ void get(const float* exch, int slot, int slotm, bool xl, bool xr, float inlet_e, unsigned nb,
-                                               const float* below, const float* cur, const float* above, float* f) {
-        F2<PRESET, K - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb, below, cur, above, f);
+                                               const float* below, const float* cur, const float* above, float* f, const F2Wall& w, float U) {
+        F2<PRESET, K - 1>::template get<PLANE, WALL>(exch, slot, slotm, xl, xr, inlet_e, nb, below, cur, above, f, w, U);
         constexpr int pl = f2_plane(K);
         constexpr int cx = CX[K];
-        const bool bb = f2_bb<K>(nb, xr);     // solid neighbour: the own cell's opposite population of the same layer
+        const bool bb = f2_bb<K>(nb, xr);     // solid neighbour (or a wall): a population of the own cell, same layer
+        float own = cur[INV[K]];
+        if (WALL && PRESET == LBM_PRESET_WIND_TUNNEL_REF && (CY[K] == -1 || CZ[K] != 0)) {
+            const int kind = f2_own_kind<PRESET, K>(w);
+            own = kind == 1 ? cur[RFY[K]] : (kind == 2 ? cur[RFZ[K]] : own);
+        }
+        if (WALL && PRESET == LBM_PRESET_CAVITY && CY[K] == -1) own = w.top ? own + lid_term(K, U) : own;
         if (pl < 0) {
             const float v = K == 0 ? cur[0] : (K == 5 ? below[5] : above[6]);
-            f[K] = (K != 0 && bb) ? cur[INV[K]] : v;
+            f[K] = (K != 0 && bb) ? own : v;
         } else if (PRESET == LBM_PRESET_WIND_TUNNEL_REF) {
             float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + (cx == -1 ? slotm : slot)];
             // (read by every lane: left to itself the compiler masks the inlet lane out of the read, which costs
             // three scalar instructions and a move per direction where a select costs one)
             if (F2_OPT & 2) asm volatile("" : "+v"(v));
-            f[K] = (cx == 1 && xl) ? weight(K) * inlet_e : (bb ? cur[INV[K]] : v);
+            f[K] = (cx == 1 && xl) ? weight(K) * inlet_e : (bb ? own : v);
         } else {
             float v = exch[pl * PLANE - CY[K] * F2_LCOLS - cx + slot];
             if (F2_OPT & 2) asm volatile("" : "+v"(v));
             const bool wall = cx == 1 ? xl : (cx == -1 ? xr : false);
-            f[K] = (wall || bb) ? cur[INV[K]] : v;    // wall bounce-back likewise
+            f[K] = (wall || bb) ? own : v;            // wall bounce-back likewise
         }
     }
 };
 template <int PRESET>
 struct F2<PRESET, -1> {
-    static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, unsigned) {}
-    static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*) {}
+    template <int WALL> static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, unsigned, const F2Wall&) {}
+    template <int WALL> static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*, const F2Wall&) {}
     static __device__ __forceinline__ void unstage(const float*, int, bool, float, float*) {}
     static __device__ __forceinline__ void fix_inlet(bool, float, float*) {}
+    static __device__ __forceinline__ void fix_lid(bool, float, float*) {}
     template <int PLANE> static __device__ __forceinline__ void put(float*, int, const float*, const float*, const float*) {}
-    template <int PLANE> static __device__ __forceinline__ void get(const float*, int, int, bool, bool, float, unsigned, const float*,
-                                                                    const float*, const float*, float*) {}
+    template <int PLANE, int WALL> static __device__ __forceinline__ void get(const float*, int, int, bool, bool, float, unsigned, const float*,
+                                                                              const float*, const float*, float*, const F2Wall&, float) {}
 };
 
 // TY: rows per tile.  STAGE 1: the next layer's loads are prefetched into LDS; 0: loaded when needed.
@@ -213,46 +259,15 @@ struct F2<PRESET, -1> {
 // OBST 1: blocks may hold solid cells (an obstacle; not the walls of the domain): directions that would pull
 // from a solid cell bounce back (first step: the load address; second step: the own first-step result), solid
 // cells are computed like any other and never stored.
-template <int PRESET, int TY, int STAGE, int NBUF, int OBST>
-__global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
-                                                          const unsigned long long* __restrict__ blocks,
-                                                          const unsigned* __restrict__ nbw, Geo g, Params p,
-                                                          FusedGrid fg, unsigned long long* __restrict__ stamps) {
+// one block of the list: rows [y0, y0 + tyn) of x tile bx, second steps for the local layers [zs, ze)
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL>
+__device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* __restrict__ fout, const unsigned* __restrict__ nbw,
+                                         const Geo& g, const Params& p, int bx, int y0, int tyn, int zs, int ze, bool blk_clean) {
+    static_assert(!WALL || OBST, "the wall rules ride on the solid-neighbour bits");
     constexpr int ROWS = TY + 2;
     constexpr int PLANE = ROWS * F2_LCOLS;
     constexpr int EXCH = 16 * PLANE;
     extern __shared__ float lds[];
-    // One workgroup per block of the host's list (fused_prepare() in lbm_hip.hip: a 64 x TY tile and a run of
-    // layers whose haloed neighbourhood is plain fluid, ordered layer range / y tile / x tile; the rim path owns
-    // every other cell).  The hardware deals workgroups to the 8 XCDs round-robin in launch
-    // order, and each XCD has its own L2.  Neighbouring tiles read each other's edge lines (the halo rows and
-    // columns, the second 128-byte line of an x-shifted load), so every XCD takes ONE contiguous range of the
-    // list: the lines two tiles share are then fetched from HBM once instead of once per L2, and every XCD
-    // still gets the same number of blocks whatever the obstacles leave eligible.
-    int bx, y0, tyn, zs, ze;                                     // rows [y0, y0 + tyn); second step: local layers [zs, ze)
-    bool blk_clean;
-    {
-        // blocks[0..8]: where each XCD's range of the list starts (ranges of equal WORK, not equal count: the
-        // runs an obstacle leaves differ in length); workgroup n of XCD x takes entry n of range x, a workgroup
-        // beyond its range has nothing to do
-        const unsigned xcd = blockIdx.x & 7u, nth = blockIdx.x >> 3;
-        const unsigned first = (unsigned)blocks[xcd], end = (unsigned)blocks[xcd + 1];
-        if (nth >= end - first) return;
-        const unsigned long long e = blocks[9 + first + nth];
-        // the entry is the same for the whole workgroup: keep what is derived from it in scalar registers
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
-        // x tile : 12 | first row : 16 | rows : 4 | first second-step layer : 16 | layers : 15 | clean : 1
-        bx = (int)(lo & 0xfffu);
-        y0 = (int)((lo >> 12) & 0xffffu);
-        tyn = (int)(lo >> 28);
-        zs = (int)(hi & 0xffffu);
-        // (the host never lets a block run past zl_end; written as a min() the compiler cannot derive a minimum trip
-        // count of the layer loop from the entry's layout, which made it peel the loop and spill 18 registers)
-        ze = min(zs + (int)((hi >> 16) & 0x7fffu), fg.zl_end);
-        // bit 63: no solid cell within reach of the block (OBST form: it then reads no neighbour words at all)
-        blk_clean = (hi >> 31) != 0u;
-    }
-    if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int role = f2_role<TY>(wave);
     const int x0 = bx * 64;
@@ -261,9 +276,17 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     bool active;
     if (role < ROWS) { r = role; x = x0 + lane; active = true; }
     else { r = lane < ROWS ? lane : lane - ROWS; x = lane < ROWS ? x0 - 1 : x0 + 64; active = lane < 2 * ROWS; }
-    active = active && r <= tyn + 1 && x >= 0 && x < g.W;
-    const bool second = role >= 1 && role <= tyn && x < g.W;
     const int y = y0 - 1 + r;
+    active = active && r <= tyn + 1 && x >= 0 && x < g.W && (!WALL || (y >= 0 && y < g.H));
+    const bool second = role >= 1 && role <= tyn && x < g.W;
+    // walls: the lane's row is fixed, the layer's z flags change as the block climbs
+    const bool w_bot = WALL && y == 0, w_top = WALL && y == g.H - 1;
+    const unsigned ybits = WALL ? ((w_bot ? F2_CY_POS : 0u) | (w_top ? F2_CY_NEG : 0u)) : 0u;
+    auto wall_of = [&](int L) -> F2Wall {
+        const int zg = L - 1 + g.z0;
+        return F2Wall{w_bot, w_top, WALL && zg == 0, WALL && zg == g.Dg - 1};
+    };
+    auto layer_ok = [&](int L) { const int zg = L - 1 + g.z0; return !WALL || (zg >= 0 && zg < g.Dg); };
     const int col = x - x0 + 1;
     const int slot = r * F2_LCOLS + col;
     const bool xl = x == 0, xr = x == g.W - 1;
@@ -287,8 +310,14 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     const unsigned nb_cell = (unsigned)((active ? y : y0) * g.Wp + (active ? x : x0));
     const unsigned* nb_base = nbw + (long long)(zs - 3) * g.H * g.Wp;
     auto nb_of = [&](int L) -> unsigned {
-        if (!OBST || !active || blk_clean) return 0u;
-        return nb_base[(unsigned)(L - (zs - 3)) * (unsigned)(g.H * g.Wp) + nb_cell];
+        if (!OBST || !active) return 0u;
+        unsigned wb = 0u;
+        if (WALL) {
+            const int zg = L - 1 + g.z0;
+            wb = ybits | (zg == 0 ? F2_CZ_POS : 0u) | (zg == g.Dg - 1 ? F2_CZ_NEG : 0u);
+        }
+        if (blk_clean) return wb;
+        return nb_base[(unsigned)(L - (zs - 3)) * (unsigned)(g.H * g.Wp) + nb_cell] | wb;
     };
 
     float below[Q], cur[Q], above[Q], pf[Q];   // first-step results of layers L-2, L-1, L; the loads of layer L
@@ -298,8 +327,8 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
     unsigned nb_cur = 0u, nb_above = nb_of(zs - 1), nb_next = nb_of(zs);
     if (STAGE) {
         const unsigned off = off_of(zs - 1);
-        if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
-            F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage_lds);
+        if (active && layer_ok(zs - 1) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
+            F2<PRESET, Q - 1>::template issue<WALL>(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage_lds, wall_of(zs - 1));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     int buf = 0;
@@ -308,23 +337,25 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         if (F2_OPT & 8) asm volatile("" : "+s"(stage_lds), "+s"(plane_s));
         // ---- first step of layer L ---------------------------------------------------------------------
         // (OBST: a wave whose cells of this layer are all solid neither loads nor collides: wave-uniform)
-        if (active && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
+        // (WALL: a layer outside the domain -- below its first, above its last -- has no first step)
+        if (active && layer_ok(L) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
             if (STAGE) {
                 F2<PRESET, Q - 1>::unstage(stage, lane, xl, inlet_e, pf);
             } else {
                 const unsigned off = off_of(L);
-                F2<PRESET, Q - 1>::load(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, pf);
+                F2<PRESET, Q - 1>::template load<WALL>(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, pf, wall_of(L));
             }
             F2<PRESET, Q - 1>::fix_inlet(xl, inlet_e, pf);
+            if (WALL) F2<PRESET, Q - 1>::fix_lid(w_top, p.U, pf);
             F2_COLLIDE(pf, above);
         }
         if (STAGE) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area has been read: refill it
-            if (active && L < ze && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
+            if (active && L < ze && layer_ok(L + 1) && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
                 const unsigned off = off_of(L + 1);
-                // (most waves have no solid cell in reach: they take the plain form of the loads, wave-uniformly)
-                if (!OBST || __ballot(nb_next != 0u) == 0ull) F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, 0u, stage_lds);
-                else F2<PRESET, Q - 1>::issue(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage_lds);
+                // (most waves have no solid cell or wall in reach: they take the plain form of the loads, wave-uniformly)
+                if (!OBST || __ballot(nb_next != 0u) == 0ull) F2<PRESET, Q - 1>::template issue<0>(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, 0u, stage_lds, F2Wall{});
+                else F2<PRESET, Q - 1>::template issue<WALL>(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_next, stage_lds, wall_of(L + 1));
             }
         }
         const unsigned nb_next2 = L + 2 <= ze ? nb_of(L + 2) : 0u;
@@ -336,9 +367,9 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
             if (second && (!OBST || __ballot(second && !(nb_cur & 1u)) != 0ull)) {
                 float f[Q], o[Q];
                 if (!OBST || __ballot(nb_cur != 0u) == 0ull)
-                    F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, 0u, below, cur, above, f);
+                    F2<PRESET, Q - 1>::template get<PLANE, 0>(exch, slot, slotm, xl, xr, inlet_e, 0u, below, cur, above, f, F2Wall{}, p.U);
                 else
-                    F2<PRESET, Q - 1>::template get<PLANE>(exch, slot, slotm, xl, xr, inlet_e, nb_cur, below, cur, above, f);
+                    F2<PRESET, Q - 1>::template get<PLANE, WALL>(exch, slot, slotm, xl, xr, inlet_e, nb_cur, below, cur, above, f, wall_of(L - 1), p.U);
                 F2_COLLIDE(f, o);
                 // the staged loads have had the whole second step to land; waiting for them HERE keeps the
                 // latency of the stores below out of the next iteration (stores count in vmcnt too)
@@ -365,5 +396,51 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         for (int k = 0; k < Q; k++) { below[k] = cur[k]; cur[k] = above[k]; }
         nb_cur = nb_above; nb_above = nb_next; nb_next = nb_next2;
     }
+}
+
+// WALL 1 (with OBST 1): blocks may lie on the domain's y and z walls; the rows / layers outside the domain take no part,
+// and the wall rules ride on the solid-neighbour bits (F2Wall).  The wind tunnel's outlet tile column keeps off the
+// walls (host side): its outlet branch indexes past the row / layer there (quirk Q2) into cells no block holds.
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL>
+__global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
+                                                          const unsigned long long* __restrict__ blocks,
+                                                          const unsigned* __restrict__ nbw, Geo g, Params p,
+                                                          FusedGrid fg, unsigned long long* __restrict__ stamps) {
+    // One workgroup per block of the host's list (fused_prepare() in lbm_hip.hip: a 64 x TY tile and a run of
+    // layers whose haloed neighbourhood is plain fluid, ordered layer range / y tile / x tile; the rim path owns
+    // every other cell).  The hardware deals workgroups to the 8 XCDs round-robin in launch
+    // order, and each XCD has its own L2.  Neighbouring tiles read each other's edge lines (the halo rows and
+    // columns, the second 128-byte line of an x-shifted load), so every XCD takes ONE contiguous range of the
+    // list: the lines two tiles share are then fetched from HBM once instead of once per L2, and every XCD
+    // still gets the same number of blocks whatever the obstacles leave eligible.
+    int bx, y0, tyn, zs, ze;                                     // rows [y0, y0 + tyn); second step: local layers [zs, ze)
+    bool blk_clean, blk_plain;
+    {
+        // blocks[0..8]: where each XCD's range of the list starts (ranges of equal WORK, not equal count: the
+        // runs an obstacle leaves differ in length); workgroup n of XCD x takes entry n of range x, a workgroup
+        // beyond its range has nothing to do
+        const unsigned xcd = blockIdx.x & 7u, nth = blockIdx.x >> 3;
+        const unsigned first = (unsigned)blocks[xcd], end = (unsigned)blocks[xcd + 1];
+        if (nth >= end - first) return;
+        const unsigned long long e = blocks[9 + first + nth];
+        // the entry is the same for the whole workgroup: keep what is derived from it in scalar registers
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)e), hi = __builtin_amdgcn_readfirstlane((unsigned)(e >> 32));
+        // x tile : 12 | first row : 16 | rows : 4 | first second-step layer : 16 | layers : 14 | plain : 1 | clean : 1
+        bx = (int)(lo & 0xfffu);
+        y0 = (int)((lo >> 12) & 0xffffu);
+        tyn = (int)(lo >> 28);
+        zs = (int)(hi & 0xffffu);
+        // (the host never lets a block run past zl_end; written as a min() the compiler cannot derive a minimum trip
+        // count of the layer loop from the entry's layout, which made it peel the loop and spill 18 registers)
+        ze = min(zs + (int)((hi >> 16) & 0x3fffu), fg.zl_end);
+        // bit 63: no solid cell within reach of the block (OBST form: it then reads no neighbour words at all)
+        blk_clean = (hi >> 31) != 0u;
+        // bit 62: neither a solid cell nor a wall of the domain within reach: the block runs the plain form of the loop
+        // inside the obstacle / wall forms of the kernel too (those cost 1.7 % / 2.5 % on a block that needs neither)
+        blk_plain = ((hi >> 30) & 1u) != 0u;
+    }
+    if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (OBST && blk_plain) f2_block<PRESET, TY, STAGE, NBUF, 0, 0>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, true);
+    else f2_block<PRESET, TY, STAGE, NBUF, OBST, WALL>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, blk_clean);
     if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }

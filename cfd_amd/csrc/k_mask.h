@@ -14,20 +14,23 @@ __global__ void k_tile_flags(const unsigned long long* __restrict__ mask, unsign
     unsigned char fl = 0;
     const int cnt = min(64, g.W - xs * 64);
     const unsigned long long all = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    // 0: interior tile, nothing solid within reach (the kernels' fast path); 1: a solid cell within reach; 2: all solid;
+    // 3: on a wall of the domain, nothing solid within reach (the one-step kernels treat it like 1; the two-step
+    // planner tells walls from obstacles by it)
     if ((mask[((long long)(z + 1) * g.H + y) * g.Wm + xs] & all) == all) {
         fl = 2;
-    } else if (y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1) {
-        fl = 1;
     } else {
         unsigned long long any = 0;
         for (int dz = -1; dz <= 1; dz++)
             for (int dy = -1; dy <= 1; dy++) {
+                if (y + dy < 0 || y + dy >= g.H) continue;     // (the ghost layers of the mask always exist)
                 const unsigned long long* r = mask + ((long long)(z + 1 + dz) * g.H + (y + dy)) * g.Wm;
                 any |= r[xs];
                 if (xs > 0) any |= r[xs - 1] >> 63;
                 if (xs + 1 < g.Wm) any |= r[xs + 1] & 1ull;
             }
-        fl = any != 0;
+        const bool wall = y == 0 || y == g.H - 1 || zg == 0 || zg == g.Dg - 1;
+        fl = any != 0 ? 1 : (wall ? 3 : 0);
     }
     flags[ti] = fl;
 }

@@ -122,6 +122,8 @@ struct lbm_ctx {
     int f2_ny = 0;                 // LBM_FUSED_NY: y tiles per tile column (0 = chosen by fused_prepare)
     unsigned long long* f2_stamps = nullptr;   // lbm_fused_chain_stamps(): start / end clock of every workgroup of one launch
     bool f2_obst_blocks = false;   // some block of the current list holds or touches solid cells
+    bool f2_walls = false;         // LBM_FUSED_WALLS=1: blocks may lie on the domain's walls (WALL form of k_fused2; measured: pays for large cavities only, profiles/r03_tuning.md)
+    bool f2_wall_blocks = false;   // the current list was planned with blocks on the walls: the WALL form of the kernel
     unsigned* f2_nbw = nullptr;    // one word per cell: which directions bounce back from a solid neighbour (k_f2_nb_words)
     FusedGrid fg{};
     float* ft = nullptr;           // third population buffer: holds time t+1 on the rim between its two steps
@@ -466,10 +468,10 @@ static bool fused_applies_slab(const lbm_ctx* c) {   // lbm_pair_*() on a z-slab
 struct F2Variant { int ty, stage, nbuf; };
 static const F2Variant kF2Variants[] = {{9, 1, 2}, {12, 1, 1}, {13, 1, 1}, {9, 0, 2}, {12, 0, 2}};
 
-template <int PRESET, int TY, int STAGE, int NBUF, int OBST>
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL>
 static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout) {
     static bool attr_set[MAX_DEVICES] = {false};
-    auto kern = k_fused2<PRESET, TY, STAGE, NBUF, OBST>;
+    auto kern = k_fused2<PRESET, TY, STAGE, NBUF, OBST, WALL>;
     const size_t lds = f2_lds_bytes(TY, STAGE, NBUF);
     if (!attr_set[c->device]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -482,9 +484,11 @@ static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout)
 }
 template <int PRESET, int TY, int STAGE, int NBUF>
 static hipError_t launch_fused_variant(lbm_ctx* c, const float* fin, float* fout) {
-    // blocks that hold solid cells need the bounce-back form of the kernel; a domain without obstacles keeps the plain one
-    return c->f2_obst_blocks ? launch_fused_kernel<PRESET, TY, STAGE, NBUF, 1>(c, fin, fout)
-                             : launch_fused_kernel<PRESET, TY, STAGE, NBUF, 0>(c, fin, fout);
+    // blocks that hold solid cells need the bounce-back form of the kernel, blocks on the domain's walls the wall form
+    // of that; a domain without either keeps the plain one
+    if (c->f2_wall_blocks) return launch_fused_kernel<PRESET, TY, STAGE, NBUF, 1, 1>(c, fin, fout);
+    return c->f2_obst_blocks ? launch_fused_kernel<PRESET, TY, STAGE, NBUF, 1, 0>(c, fin, fout)
+                             : launch_fused_kernel<PRESET, TY, STAGE, NBUF, 0, 0>(c, fin, fout);
 }
 template <int TY, int STAGE, int NBUF>
 static hipError_t launch_fused_preset(lbm_ctx* c, const float* fin, float* fout) {
@@ -560,7 +564,25 @@ static int fused_prepare(lbm_ctx* c) {
     if (fg.y_end - fg.y_first < 1) return LBM_OK;
     fg.zl_first = g.slab ? 2 : 3;                                   // widest possible range of second-step layers:
     fg.zl_end = g.slab ? g.D : g.D - 1;                             // a slab's outer layers are its boundary layers, a domain's its walls
-    if (g.H >= (1 << 16) || g.D + 2 >= (1 << 15)) return LBM_OK;    // block list entry: 16 bits each for the first row and first layer, 15 for the layers
+    // With the WALL form of the kernel (k_fused2.h) the blocks reach the walls: every row that is not solid throughout
+    // (the wind tunnel's floor plane is) and, in an undecomposed domain, every layer.  The wind tunnel's outlet tile
+    // column stays inside the bounds above (yo_first .. zo_end: its blocks must not hold a wall cell).
+    const bool walls = c->f2_walls && c->f2_obst;
+    const int yo_first = fg.y_first, yo_end = fg.y_end;
+    if (walls) {
+        auto row_solid = [&](int y) {
+            for (int z = 0; z < g.D; z++)
+                for (int xs = 0; xs < g.Wt; xs++)
+                    if (fl[tile(xs, y, z)] != 2) return false;
+            return true;
+        };
+        fg.y_first = 0;
+        while (fg.y_first < g.H / 4 && row_solid(fg.y_first)) fg.y_first++;
+        fg.y_end = g.H;
+        while (fg.y_end > g.H - g.H / 4 && row_solid(fg.y_end - 1)) fg.y_end--;
+        if (!g.slab) { fg.zl_first = 1; fg.zl_end = g.D + 1; }
+    }
+    if (g.H >= (1 << 16) || g.D + 2 >= (1 << 14)) return LBM_OK;    // block list entry: 16 bits each for the first row and first layer, 14 for the layers
 
     // ---- the plan: y tiles, runs, blocks, launch order ------------------------------------------------------------
     // A tile takes at most TY rows and a CU holds one workgroup (132 KB of LDS), so a launch runs in rounds of `ncu`
@@ -579,25 +601,28 @@ static int fused_prepare(lbm_ctx* c) {
     if (const char* t = getenv("LBM_FUSED_ROWCOST")) row_cost = atof(t);
     constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
     struct YTile { int y0, n; };
-    struct Run { int bx, by, a, len; size_t dirty; };   // dirty: where its layers' obstacle counts start in Plan::dirty
-    struct Block { unsigned bx, by, zs, len, clean; };   // clean: no solid cell within reach of its first steps
+    struct Run { int bx, by, y0, n, a, len; size_t dirty; };   // rows [y0, y0 + n) of y tile `by`; dirty: where its layers' obstacle counts start in Plan::dirty
+    struct Block { unsigned bx, by, y0, n, zs, len, clean, plain; };   // clean: no solid cell within reach of its first steps; plain: no wall of the domain either
     struct Plan {
         std::vector<YTile> ytile;
         std::vector<Run> runs;
         std::vector<int> dirty;          // per run: running count of its first-step layers (a .. a + len + 1) that an obstacle reaches
         std::vector<Block> all;          // in launch order: eight ranges, one per XCD
         size_t range[9] = {0};
-        bool obst_blocks = false;
+        bool obst_blocks = false, any_dirty = false;
         int zchunk = 0;
         double makespan = 1e300, covered = 0.0;
     };
     const bool obst = c->f2_obst;
+    // LBM_FUSED_FORM (probes): 1 = the obstacle form of the kernel, 2 = its wall form, whatever the plan needs
+    const int force_form = (c->probe && getenv("LBM_FUSED_FORM")) ? atoi(getenv("LBM_FUSED_FORM")) : 0;
 
     // rows dealt evenly, the taller tiles spread over the height (and so over the XCDs' ranges)
-    auto make_tiles = [&](int ny, Plan& pl) {
+    // (`used` < rows: only the lowest `used` rows are tiled, the rest is left to the rim)
+    auto make_tiles = [&](int ny, int used, Plan& pl) {
         pl.ytile.resize((size_t)ny);
         for (int i = 0, y = fg.y_first; i < ny; i++) {
-            pl.ytile[(size_t)i] = {y, (int)((long long)rows * (i + 1) / ny - (long long)rows * i / ny)};
+            pl.ytile[(size_t)i] = {y, (int)((long long)used * (i + 1) / ny - (long long)used * i / ny)};
             y += pl.ytile[(size_t)i].n;
         }
     };
@@ -609,12 +634,14 @@ static int fused_prepare(lbm_ctx* c) {
     // from a solid cell's frozen values); without it every tile in reach must be an interior tile (flag 0).
     // A run of usable layers [a, b] carries second steps for the layers a+1 .. b-1; layers in which most of the
     // block is solid are not worth a pass and end a run as well.
-    auto tiles_clean = [&](const Plan& pl, int bx, int by, int z_first, int z_last) {   // 0-based layers of first steps
-        const int y0 = pl.ytile[(size_t)by].y0, tyn = pl.ytile[(size_t)by].n;
-        for (int z = z_first; z <= z_last; z++)
-            for (int y = y0 - 1; y <= y0 + tyn; y++)
-                for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++)
-                    if (fl[tile(xs, y, z)] != 0) return false;
+    // (`wall_ok`: rows and layers outside the domain and wall tiles with nothing solid in reach, flag 3, count as clean)
+    auto tiles_clean = [&](int bx, int y0, int tyn, int z_first, int z_last, bool wall_ok) {   // 0-based layers of first steps
+        for (int z = std::max(z_first, wall_ok ? 0 : z_first); z <= std::min(z_last, wall_ok ? g.D - 1 : z_last); z++)
+            for (int y = std::max(y0 - 1, wall_ok ? 0 : y0 - 1); y <= std::min(y0 + tyn, wall_ok ? g.H - 1 : y0 + tyn); y++)
+                for (int xs = std::max(0, bx - 1); xs <= std::min(g.Wt - 1, bx + 1); xs++) {
+                    const unsigned char f = fl[tile(xs, y, z)];
+                    if (f != 0 && !(wall_ok && f == 3)) return false;
+                }
         return true;
     };
     auto find_runs = [&](Plan& pl) {
@@ -622,12 +649,26 @@ static int fused_prepare(lbm_ctx* c) {
         std::vector<std::vector<Run>> runs_of((size_t)ny);
 #pragma omp parallel for schedule(dynamic, 1)
         for (int by = 0; by < ny; by++) {
-            const int y0 = pl.ytile[(size_t)by].y0, tyn = pl.ytile[(size_t)by].n;
             for (int bx = 0; bx < fg.nbx; bx++) {
-                const bool outlet_tile = c->preset == LBM_PRESET_WIND_TUNNEL_REF && bx == g.Wt - 1;
-                auto clean = [&](int z) { return tiles_clean(pl, bx, by, z, z); };
+                // the wind tunnel's outlet lane copies from its own column, off the row / layer at a wall (quirk Q2) and
+                // possibly from a solid cell's frozen values: the tile column that holds it -- and the one whose halo
+                // column it is, when the last tile is one cell wide -- takes interior tiles only, trimmed to the rows
+                // that keep off the walls
+                const bool outlet_tile = c->preset == LBM_PRESET_WIND_TUNNEL_REF &&
+                                         (bx == g.Wt - 1 || (walls && bx == g.Wt - 2 && (g.W - 1) % 64 == 0));
+                int y0 = pl.ytile[(size_t)by].y0, tyn = pl.ytile[(size_t)by].n;
+                if (walls && outlet_tile) {
+                    const int ya = std::max(y0, yo_first), yb = std::min(y0 + tyn, yo_end);
+                    if (yb - ya < std::min(4, tyn)) continue;          // a sliver: left to the rim
+                    y0 = ya; tyn = yb - ya;
+                }
+                const bool wall_ok = walls && !outlet_tile;
+                // (with walls in reach of the blocks, an undecomposed domain has a virtual usable layer either side)
+                const int z_lo = (wall_ok && !g.slab) ? -1 : 0, z_hi = (wall_ok && !g.slab) ? g.D : g.D - 1;
                 auto usable = [&](int z) {   // as a layer of first steps
-                    if (!obst || outlet_tile) return clean(z);
+                    if (z < 0 || z >= g.D) return true;
+                    if (!obst || outlet_tile) return tiles_clean(bx, y0, tyn, z, z, false);
+                    if (wall_ok) return true;
                     const int zg = z + g.z0;
                     return zg > 0 && zg < g.Dg - 1;
                 };
@@ -637,18 +678,18 @@ static int fused_prepare(lbm_ctx* c) {
                     for (int y = y0; y < y0 + tyn; y++) fluid += fl[tile(bx, y, z)] != 2;
                     return fluid * 3 >= tyn;   // (thresholds from 1 % to 100 % of the rows move configs[2] by under 1 %)
                 };
-                int z = 0;
-                while (z < g.D) {
+                int z = z_lo;
+                while (z <= z_hi) {
                     if (!usable(z)) { z++; continue; }
                     const int a = z;
-                    while (z < g.D && usable(z)) z++;
+                    while (z <= z_hi && usable(z)) z++;
                     const int b = z - 1;                                 // usable layers [a, b] (0-based): second steps a+1 .. b-1
                     int s = a + 1;
                     while (s <= b - 1) {
                         if (!wanted(s)) { s++; continue; }
                         int e = s;
                         while (e + 1 <= b - 1 && wanted(e + 1)) e++;
-                        if (e - s + 1 >= MIN_LAYERS) runs_of[(size_t)by].push_back({bx, by, s - 1, e - s + 1, 0});
+                        if (e - s + 1 >= MIN_LAYERS) runs_of[(size_t)by].push_back({bx, by, y0, tyn, s - 1, e - s + 1, 0});
                         s = e + 1;
                     }
                 }
@@ -657,7 +698,8 @@ static int fused_prepare(lbm_ctx* c) {
         pl.runs.clear();
         for (auto& v : runs_of) pl.runs.insert(pl.runs.end(), v.begin(), v.end());
         // which first-step layers of a run an obstacle reaches: a block none of whose layers is reached reads no
-        // neighbour words (k_fused2.h), and a launch without any such layer takes the plain form of the kernel
+        // neighbour words (k_fused2.h), and a launch without any such layer (and without walls) takes the plain form
+        // of the kernel
         size_t total = 0;
         for (Run& r : pl.runs) { r.dirty = total; total += (size_t)r.len + 3; }
         pl.dirty.assign(total, 0);
@@ -667,15 +709,16 @@ static int fused_prepare(lbm_ctx* c) {
             for (long long i = 0; i < (long long)pl.runs.size(); i++) {
                 const Run& r = pl.runs[(size_t)i];
                 int* d = pl.dirty.data() + r.dirty;
-                for (int j = 0; j < r.len + 2; j++) d[j + 1] = d[j] + (tiles_clean(pl, r.bx, r.by, r.a + j, r.a + j) ? 0 : 1);
+                for (int j = 0; j < r.len + 2; j++) d[j + 1] = d[j] + (tiles_clean(r.bx, r.y0, r.n, r.a + j, r.a + j, walls) ? 0 : 1);
                 any = any || d[r.len + 2] > 0;
             }
         }
-        pl.obst_blocks = any;
+        pl.any_dirty = any;
+        pl.obst_blocks = any || walls || force_form >= 1;
     };
     // blocks of at most `zchunk` layers, in launch order, and the launch played through
     auto block_cost = [&](const Plan& pl, const Block& k) {
-        return (double)(k.len + 2) * (pl.ytile[k.by].n + row_cost) * ((pl.obst_blocks && !k.clean) ? 1.06 : 1.0);
+        return (double)(k.len + 2) * (k.n + row_cost) * ((pl.obst_blocks && !k.clean) ? 1.06 : ((pl.obst_blocks && !k.plain) ? 1.025 : 1.0));
     };
     auto cut_blocks = [&](Plan& pl, int zchunk) {
         pl.zchunk = zchunk;
@@ -688,9 +731,12 @@ static int fused_prepare(lbm_ctx* c) {
                 const int n = std::min(per, r.len - s0);
                 const int zs = r.a + 1 + s0 + 1;                     // local layer index (ghost offset): z + 1
                 const int* d = pl.dirty.data() + r.dirty;            // first steps: 0-based layers zs - 2 .. zs - 1 + n = run layers s0 .. s0 + n + 1
-                pl.all.push_back({(unsigned)r.bx, (unsigned)r.by, (unsigned)zs, (unsigned)n,
-                                  (unsigned)(pl.obst_blocks && d[s0 + n + 2] - d[s0] == 0 ? 1 : 0)});
-                pl.covered += (double)n * pl.ytile[(size_t)r.by].n;
+                const unsigned clean = pl.obst_blocks && d[s0 + n + 2] - d[s0] == 0 ? 1 : 0;
+                // first steps: rows y0 - 1 .. y0 + n, local layers zs - 1 .. zs + n: none of them on a wall of the domain
+                const bool off_walls = r.y0 - 1 >= 1 && r.y0 + r.n <= g.H - 2 && (zs - 2) + g.z0 >= 1 && (zs + n - 1) + g.z0 <= g.Dg - 2;
+                pl.all.push_back({(unsigned)r.bx, (unsigned)r.by, (unsigned)r.y0, (unsigned)r.n, (unsigned)zs, (unsigned)n, clean,
+                                  (unsigned)(clean && off_walls ? 1 : 0)});
+                pl.covered += (double)n * r.n;
             }
         }
         // launch order: by layer range first, then y tile, then x tile, so that the workgroups that run together
@@ -732,16 +778,23 @@ static int fused_prepare(lbm_ctx* c) {
     Plan best;
     {
         const int ny_min = (rows + TY - 1) / TY;
-        std::vector<int> ny_candidates;
-        if (c->f2_ny > 0) ny_candidates.push_back(std::min(rows, std::max(ny_min, c->f2_ny)));
-        else for (int n = ny_min; n <= std::min(rows, ny_min + ny_min / 2 + 1); n++) ny_candidates.push_back(n);
+        // candidates: (tiles, rows they cover).  Full tiles only, the remainder of the rows left to the rim, can be the
+        // better deal: 256 rows are 21 tiles of 12 + 4 rows, and 4 x 21 tile columns in three pieces each are 252
+        // blocks = one round on 256 CUs, where 22 tiles make 264
+        std::vector<std::pair<int, int>> ny_candidates;
+        if (c->f2_ny > 0) ny_candidates.push_back({std::min(rows, std::max(ny_min, c->f2_ny)), rows});
+        else {
+            if (rows % TY != 0 && rows / TY >= 1) ny_candidates.push_back({rows / TY, rows / TY * TY});
+            for (int n = ny_min; n <= std::min(rows, ny_min + ny_min / 2 + 1); n++) ny_candidates.push_back({n, rows});
+        }
         // what a candidate leaves to the rim costs two single steps there: about 2.5 x its share of a fused pass
         const double full = (double)rows * layers_all * fg.nbx;
         double best_score = 1e300;
-        int best_ny = 0, best_zc = 0;
-        for (int ny : ny_candidates) {
+        int best_ny = 0, best_zc = 0, best_used = 0;
+        for (const auto& cand : ny_candidates) {
+            const int ny = cand.first;
             Plan pl;
-            make_tiles(ny, pl);
+            make_tiles(ny, cand.second, pl);
             find_runs(pl);
             if (pl.runs.empty()) continue;
             int longest = 0;
@@ -762,11 +815,11 @@ static int fused_prepare(lbm_ctx* c) {
                 if (const char* dbg = getenv("LBM_FUSED_DEBUG"))
                     if (dbg[0] == '3') fprintf(stderr, "[fused]   candidate: %d y tiles, pieces of %d layers: %zu blocks, launch %.0f, covered %.0f of %.0f, score %.0f\n",
                                                ny, zc, pl.all.size(), pl.makespan, pl.covered, full, score);
-                if (score < best_score * (1.0 - 1e-9)) { best_score = score; best_ny = ny; best_zc = zc; }
+                if (score < best_score * (1.0 - 1e-9)) { best_score = score; best_ny = ny; best_zc = zc; best_used = cand.second; }
             }
         }
         if (best_ny == 0) return LBM_OK;
-        make_tiles(best_ny, best);
+        make_tiles(best_ny, best_used, best);
         find_runs(best);
         cut_blocks(best, best_zc);
     }
@@ -778,11 +831,12 @@ static int fused_prepare(lbm_ctx* c) {
     fg.nby = (int)ytile.size();
     fg.zchunk = zchunk;
     c->f2_obst_blocks = best.obst_blocks;
+    c->f2_wall_blocks = walls || force_form >= 2;
 
     std::vector<unsigned char> covered((size_t)ntiles, 0);
     long long fused_cells = 0;
     for (const Block& k : all) {
-        const int y0 = ytile[k.by].y0, tyn = ytile[k.by].n;
+        const int y0 = (int)k.y0, tyn = (int)k.n;
         for (int zz = (int)k.zs - 1; zz < (int)(k.zs - 1 + k.len); zz++)
             for (int y = y0; y < y0 + tyn; y++) covered[tile((int)k.bx, y, zz)] = 1;
         fused_cells += (long long)std::min(64, g.W - (int)k.bx * 64) * tyn * k.len;
@@ -803,12 +857,12 @@ static int fused_prepare(lbm_ctx* c) {
     if (getenv("LBM_FUSED_DEBUG")) {   // planning summary for tools/fused_bench.py
         long long f0 = 0, f1 = 0, f2 = 0;
         for (long long i = 0; i < ntiles; i++) { f0 += fl[(size_t)i] == 0; f1 += fl[(size_t)i] == 1; f2 += fl[(size_t)i] == 2; }
-        size_t nclean = 0;
+        size_t nclean = 0, nplain = 0;
         double work = 0.0;
-        for (const Block& k : all) { nclean += k.clean; work += block_cost(best, k); }
-        fprintf(stderr, "[fused] %dx%dx%d TY %d rows [%d,%d) in %d y tiles, layers [%d,%d) tiles: %lld interior %lld boundary %lld solid; %zu runs, zchunk %d, %zu blocks (%zu clean of obstacles), "
+        for (const Block& k : all) { nclean += k.clean; nplain += k.plain; work += block_cost(best, k); }
+        fprintf(stderr, "[fused] %dx%dx%d TY %d rows [%d,%d) in %d y tiles, layers [%d,%d) tiles: %lld interior %lld boundary %lld solid; %zu runs, zchunk %d, %zu blocks (%zu clean of obstacles, %zu of walls too), "
                 "planned launch %.0f against %.0f for perfectly spread work, fused %.1f %% of cells\n",
-                g.W, g.H, g.D, TY, fg.y_first, fg.y_end, fg.nby, fg.zl_first, fg.zl_end, f0, f1, f2, runs.size(), zchunk, all.size(), nclean,
+                g.W, g.H, g.D, TY, fg.y_first, fg.y_end, fg.nby, fg.zl_first, fg.zl_end, f0, f1, f2, runs.size(), zchunk, all.size(), nclean, nplain,
                 best.makespan, work / (8 * std::max(1, ncu / 8)), 100.0 * (double)fused_cells / (double)cells(c));
         std::vector<long long> per_by((size_t)fg.nby, 0);
         for (const Run& r : runs) per_by[(size_t)r.by] += r.len;
@@ -828,10 +882,15 @@ static int fused_prepare(lbm_ctx* c) {
         }
         fg.nblocks = (int)(8 * longest);
     }
+    if (const char* dbg = getenv("LBM_FUSED_DEBUG"))
+        if (dbg[0] == '4')   // the block list in launch order (tools/chain_spread.py --blocks joins it with the stamps)
+            for (int xcd = 0; xcd < 8; xcd++)
+                for (size_t i = best.range[xcd]; i < best.range[xcd + 1]; i++)
+                    fprintf(stderr, "[fused-block] %zu %u %u %u %u %u %u\n", 8 * (i - best.range[xcd]) + (size_t)xcd, all[i].bx, all[i].y0, all[i].n, all[i].zs, all[i].len, all[i].clean);
     blocks.reserve(9 + all.size());
     for (const Block& k : all)
-        blocks.push_back((unsigned long long)k.bx | ((unsigned long long)ytile[k.by].y0 << 12) | ((unsigned long long)ytile[k.by].n << 28) |
-                         ((unsigned long long)k.zs << 32) | ((unsigned long long)k.len << 48) | ((unsigned long long)k.clean << 63));
+        blocks.push_back((unsigned long long)k.bx | ((unsigned long long)k.y0 << 12) | ((unsigned long long)k.n << 28) |
+                         ((unsigned long long)k.zs << 32) | ((unsigned long long)k.len << 48) | ((unsigned long long)k.plain << 62) | ((unsigned long long)k.clean << 63));
 
     // rim = tiles the fused kernel does not cover (all-solid tiles need no update); its second step pulls
     // t+1 values from the 26 neighbouring tiles, so the first rim step covers the rim dilated by one tile
@@ -869,7 +928,7 @@ static int fused_prepare(lbm_ctx* c) {
     for (auto& l : list)
         while (l.size() % 4) l.push_back(~0ull);
 
-    if (c->f2_obst_blocks) {   // the solid-neighbour words of every cell (k_fused2.h); without them the blocks must keep clear of obstacles
+    if (best.any_dirty) {   // the solid-neighbour words of every cell (k_fused2.h); without them the blocks must keep clear of obstacles
         const size_t words = (size_t)(g.D + 2) * g.H * g.Wp;
         if (!c->f2_nbw && hipMalloc(&c->f2_nbw, words * sizeof(unsigned)) != hipSuccess) {
             (void)hipGetLastError();
@@ -1144,6 +1203,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_OBST")) c->f2_obst = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_WALLS")) c->f2_walls = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_NY")) c->f2_ny = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_PAIR_RIM_STREAM")) c->pair_rim_stream = atoi(t) != 0;
     if (const char* t = getenv("LBM_SIDE_PRIO")) c->side_prio = atoi(t) != 0;

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--car", action="store_true")
     ap.add_argument("--slab", type=int, nargs=2, default=None, metavar=("Z0", "DG"))
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--blocks", default=None, help="file with the library's [fused-block] lines (LBM_FUSED_DEBUG=4, stderr of an earlier run of the same domain): durations by kind of block")
     a = ap.parse_args()
     W, H, D = a.size
     kw = dict(z0=a.slab[0], depth_global=a.slab[1]) if a.slab else {}
@@ -56,6 +57,25 @@ def main():
     for i in range(0, n, 128):
         g = order[i:i + 128]
         print(f"    {i:5d}..{i + len(g) - 1:5d}: start {start[g].mean():8.1f}  duration {dur[g].mean():7.1f} [{dur[g].min():7.1f}, {dur[g].max():7.1f}]")
+    if a.blocks:
+        info = {}
+        for line in open(a.blocks):
+            if line.startswith("[fused-block]"):
+                v = [int(t) for t in line.split()[1:]]
+                info[v[0]] = v[1:]
+        idx = np.arange(len(st))[ran]
+        kinds = {}
+        for j, wg in enumerate(idx):
+            if wg not in info:
+                continue
+            bx, y0, n, zs, ln, clean = info[wg]
+            kind = ("bottom " if y0 == 0 else "") + ("top " if y0 + n == H else "") + ("first " if zs == 1 else "") + ("last " if zs + ln == D + 1 else "")
+            kinds.setdefault((kind or "inner ") + f"rows {n} layers {ln} clean {clean}", []).append(dur[j])
+        print("  duration by kind of block (us): count, mean, min, max, us per layer")
+        for k in sorted(kinds):
+            d = np.array(kinds[k])
+            ln = int(k.split("layers ")[1].split()[0])
+            print(f"    {k:48s} {len(d):5d}  {d.mean():7.1f} [{d.min():7.1f}, {d.max():7.1f}]  {d.mean() / (ln + 2):6.2f}")
     for x in range(8):
         e = end[np.arange(len(st))[ran] % 8 == x]
         if len(e):
