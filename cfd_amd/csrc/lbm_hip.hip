@@ -599,6 +599,10 @@ static int fused_prepare(lbm_ctx* c) {
     if (layers_all < 1) return LBM_OK;
     double row_cost = 4.0;   // (10 against 11 rows: 6 % less time per layer, tools/chain_spread.py)
     if (const char* t = getenv("LBM_FUSED_ROWCOST")) row_cost = atof(t);
+    // (measured per block they cost 0.91 / 0.88 of an inner column's; planned with that, 256^3 goes from one round of 252
+    // blocks to two of 252 and loses 8 %: blocks of different rounds do not march in step.  Left at 1 / 1)
+    double edge_cost[2] = {1.0, 1.0};
+    if (const char* t = getenv("LBM_FUSED_EDGECOST")) { edge_cost[0] = atof(t); if (const char* u = strchr(t, ',')) edge_cost[1] = atof(u + 1); else edge_cost[1] = edge_cost[0]; }
     constexpr int MIN_LAYERS = 6;   // shorter runs do not pay for their two lead-in layers: left to the rim
     struct YTile { int y0, n; };
     struct Run { int bx, by, y0, n, a, len; size_t dirty; };   // rows [y0, y0 + n) of y tile `by`; dirty: where its layers' obstacle counts start in Plan::dirty
@@ -718,7 +722,10 @@ static int fused_prepare(lbm_ctx* c) {
     };
     // blocks of at most `zchunk` layers, in launch order, and the launch played through
     auto block_cost = [&](const Plan& pl, const Block& k) {
-        return (double)(k.len + 2) * (k.n + row_cost) * ((pl.obst_blocks && !k.clean) ? 1.06 : ((pl.obst_blocks && !k.plain) ? 1.025 : 1.0));
+        // (a tile column at an x end of the domain has one halo column less to compute and no neighbour's lines to share:
+        // 256^3, three pieces per column, us per block: 497 / 546 / 546 / 480 for the four columns, tools/chain_spread.py)
+        const double edge = (k.bx == 0 ? edge_cost[0] : 1.0) * ((int)k.bx == g.Wt - 1 ? edge_cost[1] : 1.0);
+        return (double)(k.len + 2) * (k.n + row_cost) * edge * ((pl.obst_blocks && !k.clean) ? 1.06 : ((pl.obst_blocks && !k.plain) ? 1.025 : 1.0));
     };
     auto cut_blocks = [&](Plan& pl, int zchunk) {
         pl.zchunk = zchunk;

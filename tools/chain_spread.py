@@ -70,7 +70,7 @@ def main():
                 continue
             bx, y0, n, zs, ln, clean = info[wg]
             kind = ("bottom " if y0 == 0 else "") + ("top " if y0 + n == H else "") + ("first " if zs == 1 else "") + ("last " if zs + ln == D + 1 else "")
-            kinds.setdefault((kind or "inner ") + f"rows {n} layers {ln} clean {clean}", []).append(dur[j])
+            kinds.setdefault(f"bx {bx} " + (kind or "inner ") + f"rows {n} layers {ln} clean {clean}", []).append(dur[j])
         print("  duration by kind of block (us): count, mean, min, max, us per layer")
         for k in sorted(kinds):
             d = np.array(kinds[k])
