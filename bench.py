@@ -510,6 +510,24 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
         solver.close()
 
 
+def balance_slabs(slab, depth, first_ranges, first_times, measure, passes=2):
+    """Re-cut the slabs for equal measured cost (cfd_amd/slab.py balanced_ranges), measure, and re-cut once more from that
+    measurement: the cost of a layer is not constant in a slab's thickness (a launch runs in rounds of blocks), so
+    one pass can land a slab just beyond a round.  measure(ranges) -> (times per slab, result).  Returns
+    [(ranges, slowest, result)] of the partitions tried after the first, in order."""
+    tried, seen = [], [list(first_ranges)]
+    ranges, times = list(first_ranges), list(first_times)
+    for _ in range(passes):
+        cut = slab.balanced_ranges(depth, ranges, times)
+        if cut in seen:
+            break
+        seen.append(cut)
+        times, res = measure(cut)
+        tried.append((cut, max(times), res))
+        ranges = cut
+    return tried
+
+
 def sweep_single_gpu(lbm, device, budget):
     """Every other single-GPU configuration / output mode for a few steps each (N = 1 only)."""
     out = []
@@ -632,12 +650,17 @@ def main():
             # re-cut the slabs for equal measured cost and run again on that partition (cfd_amd/slab.py balanced_ranges)
             from cfd_amd import slab
             even = [tuple(x) for x in head["slab_ranges"]]
-            cut = slab.balanced_ranges(Dg, even, head["per_rank_ms_no_exchange"])
-            if cut != even:
+
+            def measure(cut):
+                r = run_slabs(lbm, (W, H, Dg), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
+                              world, rank, local_rank, dist, want_exposed=True, ranges=cut)
+                return r["per_rank_ms_no_exchange"], r
+            tried = balance_slabs(slab, Dg, even, head["per_rank_ms_no_exchange"], measure)
+            if tried:
                 first = {k: head[k] for k in ("ms_per_step", "mlups", "slab_ranges", "per_rank_ms_no_exchange", "exposed_comm_ms_per_step")}
-                head = run_slabs(lbm, (W, H, Dg), preset_name, scheme_name, obstacle, args.steps, args.warmup, args.min_seconds,
-                                 world, rank, local_rank, dist, want_exposed=True, ranges=cut)
+                head = min((t[2] for t in tried), key=lambda r: r["ms_per_step"])   # (the same on every rank: max-reduced times)
                 head["even_split"] = first
+                head["partitions_tried"] = [{"slab_ranges": [list(x) for x in t[0]], "ms_per_step": t[2]["ms_per_step"]} for t in tried]
         cells, fluid = head["cells_per_gpu"], head["fluid_cells_per_gpu"]
         D = head["slab_layers"]
     else:
@@ -687,11 +710,16 @@ def main():
                 ss = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=args.min_seconds, want_exposed=True, **kw)
                 if world > 1 and not args.no_balance:
                     even = [tuple(x) for x in ss["slab_ranges"]]
-                    cut = slab.balanced_ranges(Ds, even, ss["per_rank_ms_no_exchange"])
-                    if cut != even:
+
+                    def measure(cut):
+                        r = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=args.min_seconds, want_exposed=True, ranges=cut, **kw)
+                        return r["per_rank_ms_no_exchange"], r
+                    tried = balance_slabs(slab, Ds, even, ss["per_rank_ms_no_exchange"], measure)
+                    if tried:
                         first = {k: ss[k] for k in ("ms_per_step", "mlups", "slab_ranges", "per_rank_ms_no_exchange", "exposed_comm_ms_per_step")}
-                        ss = run_slabs(lbm, sz, "wind_tunnel", "ab", "car", min_seconds=args.min_seconds, want_exposed=True, ranges=cut, **kw)
+                        ss = min((t[2] for t in tried), key=lambda r: r["ms_per_step"])
                         ss["even_split"] = first
+                        ss["partitions_tried"] = [{"slab_ranges": [list(x) for x in t[0]], "ms_per_step": t[2]["ms_per_step"]} for t in tried]
                 ss["workload"] = (f"wind_tunnel {Ws}x{Hs}x{Ds} + voxelised car stand-in, A/B, {world} z-slabs of "
                                   f"{[d for _, d in ss['slab_ranges']]} layers (BASELINE.json configs[3])")
             except RuntimeError as e:              # set-up failed somewhere: every rank raised together (all_ranks_ok)
@@ -720,8 +748,13 @@ def main():
                 if all("ms_per_step" in x for x in reh):
                     ss["projected_efficiency_8_even_split"] = round(ss["ms_per_step"] / (8 * max(x["ms_per_step"] for x in reh)), 4)
                     if not args.no_balance:
-                        cut = slab.balanced_ranges(Ds, even, [x["ms_per_step"] for x in reh])
-                        reh = rehearse_all(cut) if cut != even else reh
+                        def measure(cut):
+                            rows = rehearse_all(cut)
+                            return [x.get("ms_per_step", 1e9) for x in rows], rows
+                        tried = balance_slabs(slab, Ds, even, [x["ms_per_step"] for x in reh], measure)
+                        if tried:
+                            ss["rehearsal_8_partitions_tried"] = [{"layers": [d for _, d in t[0]], "slowest_ms": t[1]} for t in tried]
+                            reh = min(tried, key=lambda t: t[1])[2]
                     ss["rehearsal_8"] = reh
                     if all("ms_per_step" in x for x in reh):
                         t8 = max(x["ms_per_step"] for x in reh)

@@ -184,3 +184,31 @@ def test_topology():
     assert slab.neighbours(0, 4, 0) == (3, 1) and slab.neighbours(0, 4, 3) == (2, 0)   # ring
     assert slab.neighbours(1, 4, 0) == (None, 1) and slab.neighbours(1, 4, 3) == (2, None)  # chain
     assert slab.neighbours(1, 1, 0) == (None, None) and slab.neighbours(0, 1, 0) == (0, 0)
+
+
+def test_balance_slabs_two_passes():
+    """bench.py balance_slabs: re-cut, measure, re-cut from that measurement; stops when a partition repeats"""
+    import importlib.util
+    from cfd_amd import slab
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    depth, P = 512, 8
+    layer_cost = np.where((np.arange(depth) > 150) & (np.arange(depth) < 360), 0.8, 1.0)     # a lighter middle (the car)
+
+    def times_of(ranges):      # cost of a slab, with a cliff: beyond 66 layers a slab pays for one more round of blocks
+        return [float(layer_cost[z0:z0 + d].sum()) * (1.08 if d > 66 else 1.0) for z0, d in ranges]
+    calls = []
+
+    def measure(cut):
+        calls.append(cut)
+        return times_of(cut), {"cut": cut}
+    even = [slab.slab_range(depth, P, r) for r in range(P)]
+    tried = bench.balance_slabs(slab, depth, even, times_of(even), measure)
+    assert 1 <= len(tried) <= 2 and len(calls) == len(tried)
+    for cut, slowest, res in tried:
+        assert sum(d for _, d in cut) == depth and cut[0][0] == 0 and res["cut"] == cut
+        assert slowest == max(times_of(cut))
+    assert min(t[1] for t in tried) < max(times_of(even))
+    # a uniform domain: the first re-cut is the even split again, nothing to try
+    assert bench.balance_slabs(slab, depth, even, [1.0] * P, measure) == []
