@@ -225,11 +225,11 @@ def source_hashes():
     return out
 
 
-def counter_traffic(kernel, cell_updates_per_launch):
+def counter_traffic(kernel, cell_updates_per_launch, first_step_loads=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_*_traffic.json, written
     by tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; counters cannot be read from
     inside this process).  None unless a profile of the same kernel on the same workload (equal cell updates per
-    launch) exists AND was taken on this very source (equal blob hashes)."""
+    launch, the same form of k_fused2's first-step loads) exists AND was taken on this very source (equal blob hashes)."""
     import glob
     mine = source_hashes()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_traffic.json"))):
@@ -241,6 +241,8 @@ def counter_traffic(kernel, cell_updates_per_launch):
         if t.get("kernel") != kernel or int(t.get("cell_updates_per_launch", -1)) != int(cell_updates_per_launch):
             continue
         if any(mine.get(k) != v for k, v in t.get("source_hashes", {}).items()) or not t.get("source_hashes"):
+            continue
+        if t.get("first_step_loads") != first_step_loads:
             continue
         return t, os.path.relpath(path, ROOT)
     return None, None
@@ -281,7 +283,13 @@ def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kern
            "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches_per_step, 3),
            "algorithmic_bytes_per_launch": round(algorithmic), "cell_updates_per_launch": round(updates),
            "bytes_per_cell_update": bytes_per_cell // 2 if two_step else bytes_per_cell}
-    prof, path = counter_traffic(name, round(updates))
+    # which form of its first-step loads k_fused2 settled on for this plan (timed by the library on the first launch)
+    loads = {1: "wide", 0: "narrow"}.get(stats.get("fused_wide_loads", -1)) if two_step else None
+    if loads:
+        out["first_step_loads"] = loads
+        if any(stats.get("fused_tuned_ms", [0, 0])):
+            out["first_step_loads_timed_us"] = {"narrow": round(stats["fused_tuned_ms"][0] * 1e3, 1), "wide": round(stats["fused_tuned_ms"][1] * 1e3, 1)}
+    prof, path = counter_traffic(name, round(updates), loads)
     if prof:
         traffic = prof["fetch_bytes"] + prof["write_bytes"]
         out["traffic"] = round(traffic)
@@ -386,6 +394,12 @@ def run_single(lbm, size, preset_name, scheme_name, obstacle, steps, warmup, min
             torch.cuda.synchronize()
 
         step(warmup)
+        # k_fused2 times the two forms of its first-step loads over its first launches of real work (lbm_stats
+        # fused_wide_loads: -1 while undecided): that belongs to the warm-up, not to the timed region
+        for _ in range(4):
+            if mode != "plain" or solver.stats()["fused_cells"] == 0 or solver.stats()["fused_wide_loads"] >= 0:
+                break
+            step(31)
         n, dt, dev_ms, st = timed_steps(solver, step, steps, min_seconds, fence)
         fluid = fluid_cells(solver, obstacle)
         bpc = {"plain": BYTES_PER_CELL, "rho_u": 172, "rho_u_curl": 192}[mode]
@@ -466,7 +480,9 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
             dist.barrier()
             torch.cuda.synchronize()
 
-        drv.step(warmup)
+        # (at least 97 steps = 48 pairs: k_fused2 has then settled on the form of its first-step loads, see run_single;
+        # the same count on every rank: a step is a collective)
+        drv.step(max(warmup, 97))
         n, dt, dev_ms, st = timed_steps(solver, drv.step, steps, min_seconds, fence,
                                         agree=lambda k: agree_steps(dist, k, "cuda"))
         tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")

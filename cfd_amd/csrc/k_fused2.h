@@ -40,6 +40,7 @@ struct FusedGrid {
     int y_first, y_end;     // rows [y_first, y_end) take the fused path (y_first >= 2, y_end <= H - 2)
     int zl_first, zl_end;   // local layers (ghost offset included) the blocks lie in: [3, D - 1)
     int zchunk;             // most layers a block takes
+    int wide;               // plain blocks take the wide form of the first-step loads (LBM_FUSED_WIDE=0 turns it off)
 };
 
 // populations whose first-step loads carry the non-temporal hint (bit k), as LBM_NT_SET for the one-step kernel
@@ -54,8 +55,11 @@ __host__ __device__ constexpr int f2_plane(int k) {
            k == 1 ? 4 : k == 2 ? 5 : k == 3 ? 6 : k == 4 ? 7 : k == 7 ? 8 : k == 8 ? 9 : k == 9 ? 10 : k == 10 ? 11 :
            k == 12 ? 12 : k == 13 ? 13 : k == 16 ? 14 : k == 17 ? 15 : -1;
 }
+// staging area of a wave: 64 floats per population, or F2_WIDE = 68 in the wide form of the loads (WIDE below)
+constexpr int F2_WIDE = 68;
+__host__ __device__ constexpr bool f2_wide_ok(int STAGE, int NBUF) { return STAGE == 1 && NBUF == 1; }
 __host__ __device__ constexpr size_t f2_lds_bytes(int TY, int STAGE, int NBUF) {
-    return (size_t)(NBUF * 16 * (TY + 2) * F2_LCOLS + (STAGE ? (TY + 3) * Q * 64 : 0)) * sizeof(float);
+    return (size_t)(NBUF * 16 * (TY + 2) * F2_LCOLS + (STAGE ? (TY + 3) * Q * (f2_wide_ok(STAGE, NBUF) ? F2_WIDE : 64) : 0)) * sizeof(float);
 }
 
 // Which wave plays which part.  Waves go to the four SIMDs of a CU round-robin, and a SIMD's waves share
@@ -72,12 +76,22 @@ __device__ __forceinline__ int f2_role(int wave) {   // 0 .. TY+1: row of the ha
     return wave - before + 1;
 }
 
+template <int TY>
+__device__ __forceinline__ int f2_wave_of(int role) {   // inverse of f2_role
+    int w = 0;
+    for (int i = 0; i < TY + 3; i++) w = f2_role<TY>(i) == role ? i : w;
+    return w;
+}
+
 // first step, one direction: k_stream_collide's interior gather (gather_fast) as base + 32-bit offset.
 // `base` = start of the chunk's lowest input layer; `off` / `offm` = byte offset of the lane's cell from it
 // (offm: one float to the left for the outlet lane x = W-1, whose cx = -1 directions copy from x = W-1).
 // The x shift (-cx floats) is NOT part of the address: the caller applies it as the instruction's immediate offset
 // (F2_XOFF<K> bytes), so that the scalar base + 32-bit lane offset form of the load survives (the compiler otherwise
 // builds 64-bit lane addresses for the ten x-shifted directions: two v_lshl_add_u64 each per layer).
+#ifndef F2_WIDE_LOADS
+#define F2_WIDE_LOADS 1   // 0: the wide form of the loads is not compiled in
+#endif
 #ifndef F2_OPT
 #define F2_OPT 8    // measured at 256^3 and 512x256x256 + car (profiles/r03_tuning.md): only bit 3 is worth having. bit 0: x shift as immediate offset, 1: unconditional exchange reads, 2: scalar store bases, 3: per-iteration M0 / plane stride
 #endif
@@ -180,6 +194,22 @@ struct F2 {
                                          // (the instruction's immediate offset moves the LDS address as well: taken off M0 again)
                                          (__attribute__((address_space(3))) void*)(size_t)(stage + K * 256u - F2_XOFF<K>), 4, F2_XOFF<K>, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
     }
+    // WIDE form (plain blocks): lanes 0..16 of a row wave load 16 bytes each = the 68 floats x0-2 .. x0+65 of the source
+    // row of direction K, x shift left to the unstage; `base` + `offw` = lane's 16 bytes of the row of cell (x0, y, L).
+    // The halo-column wave then issues no loads at all: it takes its cells' values from the row waves' areas.
+    static __device__ __forceinline__ void issue_wide(const char* __restrict__ base, const Geo& g, unsigned offw, unsigned stage) {
+        F2<PRESET, K - 1>::issue_wide(base, g, offw, stage);
+        const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row) * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dk + offw),
+                                         (__attribute__((address_space(3))) void*)(size_t)(stage + K * (F2_WIDE * 4u)), 16, 0, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
+    }
+    // `src`: the staging area of the wave that holds the lane's row, at the lane's column (x - (x0 - 2)); `adj`: 1 for the
+    // outlet lane, whose cx = -1 directions copy from its own column
+    static __device__ __forceinline__ void unstage_wide(const float* src, int adj, float* f) {
+        F2<PRESET, K - 1>::unstage_wide(src, adj, f);
+        if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) f[K] = src[K * F2_WIDE + 1 - adj];
+        else f[K] = src[K * F2_WIDE - CX[K]];
+    }
     // the same loads straight into registers (no prefetch)
     template <int WALL>
     static __device__ __forceinline__ void load(const char* __restrict__ base, const Geo& g, unsigned off, unsigned offm,
@@ -247,6 +277,8 @@ struct F2<PRESET, -1> {
     template <int WALL> static __device__ __forceinline__ void issue(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, unsigned, const F2Wall&) {}
     template <int WALL> static __device__ __forceinline__ void load(const char*, const Geo&, unsigned, unsigned, bool, bool, unsigned, float*, const F2Wall&) {}
     static __device__ __forceinline__ void unstage(const float*, int, bool, float, float*) {}
+    static __device__ __forceinline__ void issue_wide(const char*, const Geo&, unsigned, unsigned) {}
+    static __device__ __forceinline__ void unstage_wide(const float*, int, float*) {}
     static __device__ __forceinline__ void fix_inlet(bool, float, float*) {}
     static __device__ __forceinline__ void fix_lid(bool, float, float*) {}
     template <int PLANE> static __device__ __forceinline__ void put(float*, int, const float*, const float*, const float*) {}
@@ -260,10 +292,17 @@ struct F2<PRESET, -1> {
 // from a solid cell bounce back (first step: the load address; second step: the own first-step result), solid
 // cells are computed like any other and never stored.
 // one block of the list: rows [y0, y0 + tyn) of x tile bx, second steps for the local layers [zs, ze)
-template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL>
+// WIDE 1 (plain blocks of the staged one-buffer variants): the first-step loads in their wide form (F2<>::issue_wide).
+// Why: a CU of this kernel is bound by the line requests its L1 can keep in flight (profiles/r03_tuning.md section 6), and
+// the halo-column wave's one-sector loads -- 28 lanes x 19 populations, each in a line of its own -- are 532 of a block's
+// 1 204 read requests per layer for 2 of its 66 columns.  Loaded as part of the row they sit in they cost the two
+// neighbouring lines per row and population instead.  The row waves refill their areas once every wave has taken its
+// values out (a third barrier per layer).
+template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL, int WIDE>
 __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* __restrict__ fout, const unsigned* __restrict__ nbw,
                                          const Geo& g, const Params& p, int bx, int y0, int tyn, int zs, int ze, bool blk_clean) {
     static_assert(!WALL || OBST, "the wall rules ride on the solid-neighbour bits");
+    static_assert(!WIDE || (!OBST && f2_wide_ok(STAGE, NBUF)), "wide loads: plain blocks, staged loads, one exchange buffer");
     constexpr int ROWS = TY + 2;
     constexpr int PLANE = ROWS * F2_LCOLS;
     constexpr int EXCH = 16 * PLANE;
@@ -292,7 +331,14 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
     const bool xl = x == 0, xr = x == g.W - 1;
     const int slotm = slot - (xr ? 1 : 0);                       // outlet lane: its cx = -1 directions copy from its own column
     const float inlet_e = inlet_bracket(p.U);
-    float* stage = lds + NBUF * EXCH + wave * (Q * 64);
+    float* stage = lds + NBUF * EXCH + wave * (Q * (WIDE ? F2_WIDE : 64));
+    // WIDE: where the lane finds its cell's staged values: the area of the wave that holds its row, at its column
+    const float* wide_src = nullptr;
+    if (WIDE) {
+        const int src_wave = role < ROWS ? wave : f2_wave_of<TY>(r);
+        wide_src = lds + NBUF * EXCH + src_wave * (Q * F2_WIDE) + (x - (x0 - 2));
+    }
+    const bool row_wave = role < ROWS;
     // the staging area's LDS byte address for the LDS-DMA loads (M0).  Inside the layer loop it passes through an empty
     // asm, like the plane stride of the stores: derived per iteration by scalar adds, the 19 M0 values and 19 store
     // bases do not occupy 57 scalar registers across the loop (there are none to spare: they spilled into vector lanes)
@@ -305,6 +351,13 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
     const unsigned layer_b = (unsigned)(g.layer * 4), plane_b = (unsigned)(g.plane * 4);
     const unsigned cell_b = (unsigned)(((long long)(active ? y : y0) * g.row + (active ? x : x0)) * 4);
     auto off_of = [&](int L) { return (unsigned)(L - (zs - 3)) * layer_b + cell_b; };
+    // WIDE: lane i < 17 of a row wave loads the 16 bytes at float x0 - 2 + 4 i of its row
+    // (whatever the lane's own cell: a tile at the ragged end of a row still loads its row's 68 floats -- the padding and
+    // the next row's start are in bounds and never used)
+    const bool row_on = row_wave && role <= tyn + 1;
+    const unsigned wide_b = (unsigned)(((long long)(row_on ? y0 - 1 + role : y0) * g.row + x0) * 4 + lane * 16 - 8);
+    auto offw_of = [&](int L) { return (unsigned)(L - (zs - 3)) * layer_b + wide_b; };
+    const bool wide_loader = WIDE && row_on && lane < 17;
 
     // solid-neighbour bits of the lane's cell in layer L (0 without OBST: everything below folds away)
     const unsigned nb_cell = (unsigned)((active ? y : y0) * g.Wp + (active ? x : x0));
@@ -327,9 +380,12 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
     unsigned nb_cur = 0u, nb_above = nb_of(zs - 1), nb_next = nb_of(zs);
     if (STAGE) {
         const unsigned off = off_of(zs - 1);
-        if (active && layer_ok(zs - 1) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
+        if (WIDE) {
+            if (wide_loader) F2<PRESET, Q - 1>::issue_wide(base_in, g, offw_of(zs - 1), stage_lds);
+        } else if (active && layer_ok(zs - 1) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull))
             F2<PRESET, Q - 1>::template issue<WALL>(base_in, g, off, off - (xr ? 4u : 0u), xl, xr, nb_above, stage_lds, wall_of(zs - 1));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WIDE) __syncthreads();
     }
     int buf = 0;
     unsigned plane_s = plane_b;
@@ -338,7 +394,18 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
         // ---- first step of layer L ---------------------------------------------------------------------
         // (OBST: a wave whose cells of this layer are all solid neither loads nor collides: wave-uniform)
         // (WALL: a layer outside the domain -- below its first, above its last -- has no first step)
-        if (active && layer_ok(L) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
+        if (WIDE) {
+            // every wave takes its cells' values out of the row waves' areas; once all have (one more barrier, right
+            // behind the previous layer's last one), the row waves refill them: a whole layer ahead of their use
+            if (active) F2<PRESET, Q - 1>::unstage_wide(wide_src, xr ? 1 : 0, pf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wide_loader && L < ze) F2<PRESET, Q - 1>::issue_wide(base_in, g, offw_of(L + 1), stage_lds);
+            if (active) {
+                F2<PRESET, Q - 1>::fix_inlet(xl, inlet_e, pf);
+                F2_COLLIDE(pf, above);
+            }
+        } else if (active && layer_ok(L) && (!OBST || __ballot(active && !(nb_above & 1u)) != 0ull)) {
             if (STAGE) {
                 F2<PRESET, Q - 1>::unstage(stage, lane, xl, inlet_e, pf);
             } else {
@@ -349,7 +416,7 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
             if (WALL) F2<PRESET, Q - 1>::fix_lid(w_top, p.U, pf);
             F2_COLLIDE(pf, above);
         }
-        if (STAGE) {
+        if (STAGE && !WIDE) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area has been read: refill it
             if (active && L < ze && layer_ok(L + 1) && (!OBST || __ballot(active && !(nb_next & 1u)) != 0ull)) {
                 const unsigned off = off_of(L + 1);
@@ -391,6 +458,7 @@ __device__ __forceinline__ void f2_block(const float* __restrict__ fin, float* _
             if (NBUF == 1) __syncthreads(); else buf ^= 1;
         } else {
             if (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (WIDE) __syncthreads();   // (the two lead-in layers of a block have no second step and so no barrier of their own)
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) { below[k] = cur[k]; cur[k] = above[k]; }
@@ -440,7 +508,12 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
         blk_plain = ((hi >> 30) & 1u) != 0u;
     }
     if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-    if (OBST && blk_plain) f2_block<PRESET, TY, STAGE, NBUF, 0, 0>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, true);
-    else f2_block<PRESET, TY, STAGE, NBUF, OBST, WALL>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, blk_clean);
+    // plain blocks of the staged one-buffer variants load wide (the cavity's wall columns bounce back per lane: narrow)
+    constexpr bool CAN_WIDE = F2_WIDE_LOADS && f2_wide_ok(STAGE, NBUF);
+    const bool plain = !OBST || blk_plain;
+    const bool wide = CAN_WIDE && plain && fg.wide && (PRESET == LBM_PRESET_WIND_TUNNEL_REF || (bx > 0 && bx < g.Wt - 1));
+    if (CAN_WIDE && wide) f2_block<PRESET, TY, STAGE, NBUF, 0, 0, CAN_WIDE ? 1 : 0>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, true);
+    else if (plain) f2_block<PRESET, TY, STAGE, NBUF, 0, 0, 0>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, true);
+    else f2_block<PRESET, TY, STAGE, NBUF, OBST, WALL, 0>(fin, fout, nbw, g, p, bx, y0, tyn, zs, ze, blk_clean);
     if (stamps && threadIdx.x == 0) stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }

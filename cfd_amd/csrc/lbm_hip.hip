@@ -123,6 +123,11 @@ struct lbm_ctx {
     unsigned long long* f2_stamps = nullptr;   // lbm_fused_chain_stamps(): start / end clock of every workgroup of one launch
     bool f2_obst_blocks = false;   // some block of the current list holds or touches solid cells
     bool f2_walls = false;         // LBM_FUSED_WALLS=1: blocks may lie on the domain's walls (WALL form of k_fused2; measured: pays for large cavities only, profiles/r03_tuning.md)
+    int f2_wide = -1;              // LBM_FUSED_WIDE: 1 / 0 = plain blocks take / do not take the wide form of the first-step loads; -1 = timed on the first launch after a plan
+    bool f2_wide_pending = false;  // the current plan is still being timed (f2_wide == -1)
+    std::vector<hipEvent_t> f2_tune_ev;   // start / end events of the tuning launches so far
+    int f2_tune_n = 0;
+    float f2_wide_ms[2] = {0.f, 0.f};   // what the two forms took when they were timed (narrow, wide)
     bool f2_wall_blocks = false;   // the current list was planned with blocks on the walls: the WALL form of the kernel
     unsigned* f2_nbw = nullptr;    // one word per cell: which directions bounce back from a solid neighbour (k_f2_nb_words)
     FusedGrid fg{};
@@ -520,6 +525,7 @@ static int fused_upload(lbm_ctx* c, void** dev, size_t* cap, const void* host, s
 
 // the mask is clean (refresh_mask_state ran).  Leaves fused_usable = false when the fused path does not apply
 // to this domain or would not pay; that is not an error.
+static void fused_tune_reset(lbm_ctx* c);
 static int fused_prepare(lbm_ctx* c) {
     if (c->fused_ready) return LBM_OK;
     c->fused_ready = true;
@@ -958,6 +964,9 @@ static int fused_prepare(lbm_ctx* c) {
     }
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the host vectors go out of scope
+    fg.wide = c->f2_wide == 1 ? 1 : 0;
+    c->f2_wide_pending = c->f2_wide < 0 && f2_wide_ok(c->f2_stage, c->f2_nbuf);
+    fused_tune_reset(c);
     c->fg = fg;
     c->fused_cells = fused_cells;
     c->rim_cells = rim_cells;
@@ -967,7 +976,63 @@ static int fused_prepare(lbm_ctx* c) {
 
 // one k_fused2 launch on the context's stream; between lbm_timer_begin and lbm_timer_end it is bracketed by HIP
 // events of its own, so that the roofline figure of the dominant kernel does not include the rim's launches
+// Narrow or wide first-step loads for the plain blocks (k_fused2.h WIDE)?  Neither wins everywhere (256^3 and 512^3 wind
+// tunnel: wide +2 % / +4.5 %; 1024 x 512 x 512, thin slabs, obstacles: narrow +2-3 %; profiles/r03_tuning.md section 7), and
+// a few launches timed back to back do not predict the steady state (the rim's launches in between, what the previous
+// pair left in the caches; nor do alternating ones: each form then runs in the other's wake).  So of the first
+// launches of real work after a plan the first 16 run narrow and untimed (the first launches of a run are slower whatever
+// the form), then come 10 narrow, 10 wide and 10 narrow ones bracketed by events, and the form with the smaller mean (the
+// first 4 of each group left out: a form needs a few launches in its own wake) is kept.  Shorter runs stay narrow.
+constexpr int F2_TUNE_WARM = 16, F2_TUNE_GROUP = 10, F2_TUNE_SKIP = 4;
+constexpr int F2_TUNE_LAUNCHES = F2_TUNE_WARM + 3 * F2_TUNE_GROUP;
+static inline int f2_tune_form(int i) { return i >= F2_TUNE_WARM + F2_TUNE_GROUP && i < F2_TUNE_WARM + 2 * F2_TUNE_GROUP ? 1 : 0; }
+static inline bool f2_tune_counts(int i) { return i >= F2_TUNE_WARM && (i - F2_TUNE_WARM) % F2_TUNE_GROUP >= F2_TUNE_SKIP; }
+static void fused_tune_reset(lbm_ctx* c) {
+    for (hipEvent_t e : c->f2_tune_ev) (void)hipEventDestroy(e);
+    c->f2_tune_ev.clear();
+    c->f2_tune_n = 0;
+}
+// before launch number f2_tune_n of the tuning phase: which form it takes; after the last one, the verdict
+static int fused_tune_next(lbm_ctx* c) {
+    if (c->f2_tune_n < F2_TUNE_LAUNCHES) {
+        c->fg.wide = f2_tune_form(c->f2_tune_n);
+        return LBM_OK;
+    }
+    c->f2_wide_pending = false;
+    HIPCHK(c, hipEventSynchronize(c->f2_tune_ev.back()));
+    double sum[2] = {0.0, 0.0};
+    int cnt[2] = {0, 0};
+    for (int i = 0; i < F2_TUNE_LAUNCHES; i++) {
+        const int form = f2_tune_form(i);
+        if (!f2_tune_counts(i)) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->f2_tune_ev[2 * (size_t)i], c->f2_tune_ev[2 * (size_t)i + 1]) == hipSuccess) { sum[form] += ms; cnt[form]++; }
+    }
+    for (int f = 0; f < 2; f++) c->f2_wide_ms[f] = cnt[f] ? (float)(sum[f] / cnt[f]) : 0.f;
+    c->fg.wide = (cnt[0] && cnt[1] && c->f2_wide_ms[1] < 0.995f * c->f2_wide_ms[0]) ? 1 : 0;
+    if (getenv("LBM_FUSED_DEBUG"))
+        fprintf(stderr, "[fused] first-step loads timed over %d launches: narrow %.1f us, wide %.1f us -> %s\n", F2_TUNE_LAUNCHES,
+                c->f2_wide_ms[0] * 1e3, c->f2_wide_ms[1] * 1e3, c->fg.wide ? "wide" : "narrow");
+    fused_tune_reset(c);
+    return LBM_OK;
+}
+
 static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->f2_wide_pending) {
+        const int rc = fused_tune_next(c);
+        if (rc) return rc;
+        if (c->f2_wide_pending) {
+            if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {   // no events: no tuning
+                (void)hipGetLastError();
+                if (t0) (void)hipEventDestroy(t0);
+                t0 = t1 = nullptr;
+                c->f2_wide_pending = false; c->fg.wide = 0; fused_tune_reset(c);
+            } else {
+                c->f2_tune_ev.push_back(t0); c->f2_tune_ev.push_back(t1); c->f2_tune_n++;
+            }
+        }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->f2_ev_used + 2 > c->f2_ev.size() && c->f2_ev.size() < 1024) {
@@ -977,8 +1042,10 @@ static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
         if (c->f2_ev_used + 2 <= c->f2_ev.size()) { e0 = c->f2_ev[c->f2_ev_used]; e1 = c->f2_ev[c->f2_ev_used + 1]; c->f2_ev_used += 2; }
     }
     if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
+    if (t0) HIPCHK(c, hipEventRecord(t0, c->stream));
     hipError_t e = launch_fused(c, in, out);
     if (e != hipSuccess) return fail(c, LBM_ERR_HIP, "k_fused2 launch failed: %s", hipGetErrorString(e));
+    if (t1) HIPCHK(c, hipEventRecord(t1, c->stream));
     if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
     c->fused_launches++;
     return LBM_OK;
@@ -1211,6 +1278,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_OBST")) c->f2_obst = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_WALLS")) c->f2_walls = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_WIDE")) c->f2_wide = atoi(t) < 0 ? -1 : (atoi(t) != 0);
     if (const char* t = getenv("LBM_FUSED_NY")) c->f2_ny = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_PAIR_RIM_STREAM")) c->pair_rim_stream = atoi(t) != 0;
     if (const char* t = getenv("LBM_SIDE_PRIO")) c->side_prio = atoi(t) != 0;
@@ -1301,6 +1369,7 @@ int lbm_destroy(lbm_ctx* c) {
     hipFree(c->ob[0]); hipFree(c->ob[1]); hipFree(c->prev_mask);
     hipFree(c->ft); hipFree(c->f2_nbw); hipFree(c->f2_blocks); hipFree(c->f2_stamps); hipFree(c->rim_list[0]); hipFree(c->rim_list[1]);
     for (hipEvent_t ev : c->f2_ev) hipEventDestroy(ev);
+    fused_tune_reset(c);
     if (c->stream_rim) { hipStreamSynchronize(c->stream_rim); hipStreamDestroy(c->stream_rim); }
     if (c->ev_f2_main) hipEventDestroy(c->ev_f2_main);
     if (c->ev_f2_rim) hipEventDestroy(c->ev_f2_rim);
@@ -1945,6 +2014,9 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->rim_cells = (uint64_t)(c->fused_usable ? c->rim_cells : 0);
     out->last_timed_fused_launches = c->last_fused_launches;
     out->last_timed_fused_ms = c->last_fused_ms;
+    out->fused_wide_loads = !c->fused_usable ? -1 : (c->f2_wide_pending ? -1 : c->fg.wide);
+    out->fused_tuned_ms[0] = c->f2_wide_ms[0];
+    out->fused_tuned_ms[1] = c->f2_wide_ms[1];
     return LBM_OK;
 }
 

@@ -47,7 +47,8 @@ class Stats(C.Structure):
                 ("population_bytes", C.c_uint64), ("last_timed_ms", C.c_double),
                 ("last_timed_steps", C.c_uint64), ("last_timed_launches", C.c_uint64),
                 ("fused_cells", C.c_uint64), ("rim_cells", C.c_uint64),
-                ("last_timed_fused_launches", C.c_uint64), ("last_timed_fused_ms", C.c_double)]
+                ("last_timed_fused_launches", C.c_uint64), ("last_timed_fused_ms", C.c_double),
+                ("fused_wide_loads", C.c_int32), ("fused_tuned_ms", C.c_float * 2)]
 
 
 # every symbol include/lbm_abi.h declares, with its ctypes signature
@@ -293,7 +294,9 @@ class Solver:
     def stats(self):
         s = Stats()
         self._chk(self._lib.lbm_get_stats(self._ctx, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in Stats._fields_}
+        out["fused_tuned_ms"] = [float(x) for x in s.fused_tuned_ms]
+        return out
 
     def fused_chain_stamps(self):
         """(start, end) device-clock stamps (100 MHz) of every workgroup of one k_fused2 launch, shape (n, 2);

@@ -120,6 +120,10 @@ typedef struct lbm_stats {
     uint64_t rim_cells;           /* cells of the rim tiles, which take two one-step launches per pair instead */
     uint64_t last_timed_fused_launches; /* k_fused2 launches between timer_begin and timer_end */
     double   last_timed_fused_ms; /* their summed device time (HIP events around each launch) */
+    /* the form of k_fused2's first-step loads for blocks without obstacles in reach: timed on the first launch after a
+     * plan (LBM_FUSED_WIDE unset), neither form wins everywhere */
+    int32_t  fused_wide_loads;    /* 1 wide (16-byte loads of whole rows), 0 narrow, -1 not decided yet */
+    float    fused_tuned_ms[2];   /* what one launch took when they were timed: narrow, wide (0: never timed) */
 } lbm_stats;
 
 /* lbm_solver::lbm_solver(int,int,int)  -- lbm_solver.cu:404-453.  opts may be NULL. */

@@ -126,6 +126,40 @@ def test_fused_blocks_on_the_walls(oracle, lbm, preset, walls, monkeypatch):
         assert st["rim_cells"] >= W * 2 * (H + D), st
 
 
+@pytest.mark.parametrize("form", ["0", "1", None])
+@pytest.mark.parametrize("preset", [0, 1])
+def test_fused_first_step_load_forms(oracle, lbm, preset, form, monkeypatch):
+    """the plain blocks' first-step loads come in two forms (k_fused2.h WIDE: 16-byte loads of whole rows, the halo-column
+    wave reading the row waves' staging areas; or one dword per lane and a loading halo-column wave).  Forced either way,
+    or timed and chosen by the library (LBM_FUSED_WIDE unset), every cell equals the oracle; W ragged, x tiles at both
+    ends of the domain and inside, obstacles (whose blocks keep the narrow form) beside plain blocks"""
+    import os
+    if os.environ.get("LBM_LAYOUT") != str(lbm.LAYOUT_ROWS):
+        pytest.skip("the fused path runs on the row-interleaved layout")
+    if form is None:
+        monkeypatch.delenv("LBM_FUSED_WIDE", raising=False)
+    else:
+        monkeypatch.setenv("LBM_FUSED_WIDE", form)
+    W, H, D = 270, 40, 30
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    for s in (o, g):
+        s.init()
+        s.set_params(inlet_velocity=0.07, omega_shear=1.75, omega_bulk=1.6)
+        s.add_solid(150, 12, 8, 10, 9, 11)
+    for n in (7, 4, 95):         # 3 + 1 + 47 pairs: the library times the two forms over the first 46 launches of a plan
+        o.step(n); g.step(n)
+        same(o, g, f"preset {preset}, LBM_FUSED_WIDE {form}, after a call of {n} steps")
+        if form is None and n == 4:
+            assert g.stats()["fused_wide_loads"] == -1      # still alternating
+    st = g.stats()
+    assert st["fused_cells"] > 0
+    if form is None:
+        assert st["fused_wide_loads"] in (0, 1) and min(st["fused_tuned_ms"]) > 0, st
+    else:
+        assert st["fused_wide_loads"] == int(form) and max(st["fused_tuned_ms"]) == 0, st
+
+
 def test_fused_cube_64(oracle, lbm):
     """BASELINE.json configs[0]: 64^3 channel around assets/cube.obj, 100 steps in calls of mixed length"""
     o = oracle.Solver(64, 64, 64)

@@ -76,6 +76,7 @@ dom_stats = [r for r in stats if r["Name"] == vals["FETCH_SIZE"][2]]
 with open(os.path.join(dst, f"{prefix}_{tag}_traffic.json"), "w") as f:
     json.dump({"kernel": dominant, "kernel_symbol": "%s<%s>" % inst(vals["FETCH_SIZE"][2]), "workload": b["config"]["workload"],
                "cell_updates_per_launch": b["roofline"]["cell_updates_per_launch"],
+               "first_step_loads": b["roofline"].get("first_step_loads"),
                "fetch_bytes": fetch_b, "write_bytes": write_b, "dispatches": vals["FETCH_SIZE"][1],
                "launch_us": round(float(dom_stats[0]["AverageNs"]) / 1e3, 2) if dom_stats else None,
                "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 counts wide streaming reads at half), WRITE_SIZE KiB x1024; separate --pmc passes",
