@@ -199,7 +199,9 @@ struct F2 {
     // The halo-column wave then issues no loads at all: it takes its cells' values from the row waves' areas.
     static __device__ __forceinline__ void issue_wide(const char* __restrict__ base, const Geo& g, unsigned offw, unsigned stage) {
         F2<PRESET, K - 1>::issue_wide(base, g, offw, stage);
-        const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row) * 4;
+        // (the 68-float window starts at x0-4 for cx = +1, x0-2 for cx = 0, x0 for cx = -1: what the 66 cells of the row
+        // pull from then lies in three lines instead of four for the x-shifted directions, and on 16-byte boundaries)
+        const long long dk = ((long long)K * g.plane - (long long)CZ[K] * g.layer - (long long)CY[K] * g.row) * 4 - CX[K] * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dk + offw),
                                          (__attribute__((address_space(3))) void*)(size_t)(stage + K * (F2_WIDE * 4u)), 16, 0, ((F2_NT_SET >> K) & 1u) ? 2 : 0);
     }
@@ -207,8 +209,9 @@ struct F2 {
     // outlet lane, whose cx = -1 directions copy from its own column
     static __device__ __forceinline__ void unstage_wide(const float* src, int adj, float* f) {
         F2<PRESET, K - 1>::unstage_wide(src, adj, f);
-        if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) f[K] = src[K * F2_WIDE + 1 - adj];
-        else f[K] = src[K * F2_WIDE - CX[K]];
+        // cell at column c = x - (x0 - 2) pulls from float x - cx, which sits at slot c - cx + 2 cx of its direction's window
+        if (PRESET == LBM_PRESET_WIND_TUNNEL_REF && CX[K] == -1) f[K] = src[K * F2_WIDE - 1 - adj];
+        else f[K] = src[K * F2_WIDE + CX[K]];
     }
     // the same loads straight into registers (no prefetch)
     template <int WALL>
