@@ -18,7 +18,8 @@
 // The next layer's 19 loads travel global -> LDS (global_load_lds_dword, no registers held in flight)
 // while all this happens.
 //
-// Scope: blocks of tiles whose haloed neighbourhood keeps off the domain's walls (no wall row, no wall layer),
+// Scope: blocks of tiles whose haloed neighbourhood keeps off the domain's walls (no wall row, no wall layer; with the
+// optional WALL form of the kernel the blocks may lie on them, see F2Wall),
 // with the x ends of the domain handled in place exactly as k_stream_collide's interior path does (inlet
 // constant / outlet copy of the reference chain, lbm_solver.cu:283-296, or the cavity's wall bounce-back), and
 // -- in the OBST form of the kernel -- with solid cells inside: a direction that would pull from a solid cell
@@ -289,12 +290,13 @@ struct F2<PRESET, -1> {
                                                                               const float*, const float*, float*, const F2Wall&, float) {}
 };
 
+// One block of the list: rows [y0, y0 + tyn) of x tile bx, second steps for the local layers [zs, ze).
 // TY: rows per tile.  STAGE 1: the next layer's loads are prefetched into LDS; 0: loaded when needed.
 // NBUF 2: two exchange buffers, one barrier per layer; 1: one buffer, two barriers per layer.
 // OBST 1: blocks may hold solid cells (an obstacle; not the walls of the domain): directions that would pull
 // from a solid cell bounce back (first step: the load address; second step: the own first-step result), solid
 // cells are computed like any other and never stored.
-// one block of the list: rows [y0, y0 + tyn) of x tile bx, second steps for the local layers [zs, ze)
+// WALL 1 (with OBST 1): see k_fused2 below.
 // WIDE 1 (plain blocks of the staged one-buffer variants): the first-step loads in their wide form (F2<>::issue_wide).
 // Why: a CU of this kernel is bound by the line requests its L1 can keep in flight (profiles/r03_tuning.md section 6), and
 // the halo-column wave's one-sector loads -- 28 lanes x 19 populations, each in a line of its own -- are 532 of a block's
