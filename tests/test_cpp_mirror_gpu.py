@@ -31,11 +31,11 @@ def test_headless_driver_known_answer(tmp_path):
 
 
 @pytest.mark.parametrize("extra", [[], ["--scheme", "aa"], ["--scheme", "slide"], ["--preset", "cavity"], ["--autotune", "--steps", "120"],
-                                   ["--single-steps"]])
+                                   ["--single-steps"], ["--copy-engine"], ["--copy-engine", "--scheme", "aa"], ["--copy-engine", "--preset", "cavity"]])
 def test_native_rccl_slab_driver(extra):
     """tools/lbm_slab_rccl.cpp: C++ host, RCCL ncclSend/ncclRecv between the slabs of one process.
     On this one-GPU box the wind-tunnel ring sends to itself through RCCL; --check compares with the
-    undecomposed run bit for bit."""
+    undecomposed run bit for bit.  --copy-engine: the same exchange as peer copies ordered by events (no RCCL kernels)."""
     exe = os.path.join(CSRC, "lbm_slab_rccl")
     assert os.path.exists(exe), "build it with make -C cfd_amd/csrc"
     r = subprocess.run([exe, "--dims", "96", "48", "40", "--gpus", "1", "--steps", "25", "--obj", CUBE_OBJ, "--check"] + extra,

@@ -4,7 +4,7 @@
 // the C++ twin of cfd_amd/slab.py, which drives the same ABI from one process per GPU.
 //
 //   lbm_slab_rccl [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity]
-//                 [--scheme ab|aa|slide] [--autotune] [--single-steps] [--check]
+//                 [--scheme ab|aa|slide] [--autotune] [--single-steps] [--copy-engine] [--check]
 //
 // Per step and slab (two streams):
 //   side stream : lbm_step_boundary_layers (writes both outgoing messages) -> ncclSend/ncclRecv
@@ -52,12 +52,44 @@ struct Slab {
     lbm_ctx* ctx = nullptr;
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t main_done = nullptr, side_done = nullptr;
+    hipEvent_t ready = nullptr, sent = nullptr;   // --copy-engine: this slab's earlier work is done / its messages have been delivered
     float* send[2] = {nullptr, nullptr};  // [0] leaves through the bottom face, [1] through the top face
     float* recv[2] = {nullptr, nullptr};  // [0] arrived on the bottom face, [1] on the top face
     ncclComm_t comm = nullptr;
 };
 
+// --copy-engine: the same exchange as peer-to-peer copies (hipMemcpyPeerAsync: the SDMA engines over xGMI, no compute
+// units) instead of RCCL's send / recv kernels, which find no room beside the two-steps-per-pass kernel and wait for its
+// launch to end (profiles/r03_tuning.md section 8).  One process holds every GPU, so a sender can write its neighbour's
+// receive buffer directly; two events per slab order it: a slab's copies wait until the neighbour has got as far as this
+// exchange (its earlier unpack has consumed the buffer), and a slab goes on once its neighbours' copies have landed.
+static bool g_copy_engine = false;
+static void exchange_copies(std::vector<Slab>& slabs, size_t nfloats, bool on_side) {
+    const size_t bytes = nfloats * sizeof(float);
+    auto stream_of = [&](Slab& s) { return on_side ? s.side : s.main; };
+    for (Slab& s : slabs) { HIP_OK(hipSetDevice(s.dev)); HIP_OK(hipEventRecord(s.ready, stream_of(s))); }
+    for (Slab& s : slabs) {
+        HIP_OK(hipSetDevice(s.dev));
+        hipStream_t st = stream_of(s);
+        if (s.up >= 0) {     // leaves through the top face, arrives on the neighbour's bottom face
+            HIP_OK(hipStreamWaitEvent(st, slabs[(size_t)s.up].ready, 0));
+            HIP_OK(hipMemcpyPeerAsync(slabs[(size_t)s.up].recv[0], slabs[(size_t)s.up].dev, s.send[1], s.dev, bytes, st));
+        }
+        if (s.down >= 0) {
+            HIP_OK(hipStreamWaitEvent(st, slabs[(size_t)s.down].ready, 0));
+            HIP_OK(hipMemcpyPeerAsync(slabs[(size_t)s.down].recv[1], slabs[(size_t)s.down].dev, s.send[0], s.dev, bytes, st));
+        }
+        HIP_OK(hipEventRecord(s.sent, st));
+    }
+    for (Slab& s : slabs) {
+        HIP_OK(hipSetDevice(s.dev));
+        if (s.down >= 0) HIP_OK(hipStreamWaitEvent(stream_of(s), slabs[(size_t)s.down].sent, 0));
+        if (s.up >= 0) HIP_OK(hipStreamWaitEvent(stream_of(s), slabs[(size_t)s.up].sent, 0));
+    }
+}
+
 static void exchange(std::vector<Slab>& slabs, size_t nfloats, bool on_side) {
+    if (g_copy_engine) { exchange_copies(slabs, nfloats, on_side); return; }
     NCCL_OK(ncclGroupStart());
     for (Slab& s : slabs) {
         HIP_OK(hipSetDevice(s.dev));
@@ -85,7 +117,8 @@ int main(int argc, char** argv) {
         else if (is("--check")) check = true;
         else if (is("--autotune")) autotune = true;
         else if (is("--single-steps")) single_steps = true;
-        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--autotune] [--single-steps] [--check]\n", argv[0]); return 2; }
+        else if (is("--copy-engine")) g_copy_engine = true;
+        else { std::fprintf(stderr, "usage: %s [--dims W H D] [--gpus P] [--steps N] [--obj PATH] [--preset wind|cavity] [--scheme ab|aa|slide] [--autotune] [--single-steps] [--copy-engine] [--check]\n", argv[0]); return 2; }
     }
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
@@ -111,6 +144,11 @@ int main(int argc, char** argv) {
         HIP_OK(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&s.main_done, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&s.sent, hipEventDisableTiming));
+        if (g_copy_engine)
+            for (int q = 0; q < P; q++)
+                if (q != r) { const hipError_t e = hipDeviceEnablePeerAccess(q, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_OK(e); (void)hipGetLastError(); }
         lbm_opts o;
         std::memset(&o, 0, sizeof o);
         o.struct_size = sizeof o; o.device = r; o.preset = preset; o.scheme = scheme;
@@ -266,7 +304,7 @@ int main(int argc, char** argv) {
     sync_all();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double cells = (double)W * H * D;
-    std::printf("%dx%dx%d in %d z-slabs over RCCL (%s, %s): %d steps (%d pairs of steps in the timed part), %.3f ms/step, %.1f MLUPS\n", W, H, D, P,
+    std::printf("%dx%dx%d in %d z-slabs over %s (%s, %s): %d steps (%d pairs of steps in the timed part), %.3f ms/step, %.1f MLUPS\n", W, H, D, P, g_copy_engine ? "peer copies" : "RCCL",
                 ring ? "wind tunnel, ring" : "cavity, chain", scheme == LBM_SCHEME_AA ? "AA" : (scheme == LBM_SCHEME_SLIDE ? "sliding A/B" : "A/B"), steps + tuned,
                 paired, dt / (steps - warm) * 1e3, cells * (steps - warm) / dt / 1e6);
 
