@@ -432,13 +432,14 @@ def all_ranks_ok(dist, ok, what):
 
 
 def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmup, min_seconds, world, rank, local_rank, dist,
-              want_exposed=True, rehearse=None, ranges=None):
+              want_exposed=True, rehearse=None, ranges=None, params=None):
     """This rank's z-slab of the domain through the split step + RCCL halo exchange (cfd_amd/slab.py).  `dist` is an
     initialised torch.distributed (world 1: a ring to itself).
     rehearse = (r, P) at world 1: slab r of the P an P-GPU run would hold (layers [r D/P, (r+1) D/P) of the global
     domain, its share of the obstacle), with its RCCL ring closed on itself: the launches, message sizes and the
     two-stream schedule of rank r of P, on one GPU.
-    ranges = [(z0, layers)] per part (default: an even split)."""
+    ranges = [(z0, layers)] per part (default: an even split).  params: set_params(**params) instead of the preset's
+    defaults (tools/rehearsal_state_probe.py)."""
     import torch
     from cfd_amd import slab
     W, H, Dg = size_global
@@ -465,7 +466,9 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
         drv = slab.SlabSolver(eng, preset, world, rank, slab.HostStagedP2P() if staged else slab.TorchP2P())
         try:
             solver.init()
-            if preset == lbm.PRESET_CAVITY:
+            if params is not None:
+                solver.set_params(**params)
+            elif preset == lbm.PRESET_CAVITY:
                 solver.set_params(**CAVITY_PARAMS)
             if obstacle:
                 solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
@@ -778,7 +781,11 @@ def main():
                         ss["projected_efficiency_8"] = round(ss["ms_per_step"] / (8 * t8), 4)
                         ss["projection_note"] = ("T1 / (8 x the slowest of the eight slabs an 8-GPU run would hold), each stepped on this one "
                                                  "GPU with its RCCL ring closed on itself, slabs cut for equal measured cost as the N > 1 "
-                                                 "run cuts them; no xGMI transfer is in it")
+                                                 "run cuts them; no xGMI transfer is in it.  `state_finite` false on a slab: its ring "
+                                                 "closes on itself, so where the car's cross-section differs between its two faces "
+                                                 "the flow blows up at omega_shear 1.98; the launches and their time do not depend "
+                                                 "on the values (tools/rehearsal_state_probe.py: 0.598 ms with the reference's "
+                                                 "parameters, 0.597 with tame ones that stay finite)")
             if out is not None:
                 out["strong_scaling"] = ss
                 log("[bench] strong scaling:", json.dumps(ss))
