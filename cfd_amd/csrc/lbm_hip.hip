@@ -150,6 +150,7 @@ struct lbm_ctx {
     bool side_prio = true;         // LBM_SIDE_PRIO=0: the short kernels beside k_fused2 do not raise their waves' priority
     hipEvent_t ev_pair_b1 = nullptr, ev_pair_r1 = nullptr;
     bool pair_last = false;        // the last update was a pair: the previous buffer is TWO steps old (no rho/u on demand)
+    bool ended_on_pair = false;    // lbm_step() ended on a fused pair: f[1-cur] is two steps old, rho/u on demand take one step through ft
     std::vector<hipEvent_t> f2_ev; // event pairs around the k_fused2 launches of a timed region
     size_t f2_ev_used = 0;
     bool timing = false;
@@ -1106,6 +1107,14 @@ static int materialise_fields(lbm_ctx* c) {
         // the fields of the last step were settled with the old mask and then dropped by a window change;
         // the buffer they came from has been re-frozen with the new mask since
         return fail(c, LBM_ERR_STATE, "the mask or the populations changed since the last step: rho/u of another field window exist after the next lbm_step()");
+    } else if (c->ended_on_pair) {
+        // lbm_step() ended on a pair: f[1-cur] is the state two steps back, untouched.  One ordinary step from it into
+        // the rim's buffer gives the state the last step read; the gather from there is the one below.
+        const int K = c->ab_chunk > 0 ? c->ab_chunk : c->g.D;
+        for (int zb = 0; zb < c->g.D && !rc; zb += K)
+            rc = launch_stream_collide<0>(c, c->f[1 - c->cur], c->ft, c->p_last, 1 + zb, std::min(K, c->g.D - zb));
+        if (!rc) rc = launch_stream_collide<1>(c, c->ft, nullptr, c->p_last, 1 + c->g.fz0, c->g.fnz);
+        if (rc) return rc;
     } else {
         // the last step read f[1-cur]; it is still intact (A/B), so the same gather gives the
         // same post-stream moments (lbm_solver.cu:320-337)
@@ -1408,6 +1417,7 @@ int lbm_init(lbm_ctx* c) {
     c->fields = FIELDS_INIT;  // rho = 1, u = 0 everywhere, solid cells included (lbm_solver.cu:62-63)
     c->prev_touched = false;
     c->pair_last = false;
+    c->ended_on_pair = false;
     c->curl_valid = false;
     return LBM_OK;
 }
@@ -1600,13 +1610,18 @@ int lbm_step(lbm_ctx* c, int nsteps) {
         if (rc) return rc;
     }
     int s = 0;
-    // Two steps per pass wherever the batch allows it.  The LAST step of a call always runs alone: rho/u of
-    // that step are recomputed on demand from the buffer it read, which a fused pair would skip over.
-    if (nsteps >= 3 && fused_applies(c)) {
+    // Two steps per pass wherever the batch allows it.  When the caller wants rho/u written (fuse) or the count is
+    // odd, the LAST step of a call runs alone: rho/u of that step are recomputed on demand from the buffer it read,
+    // which a fused pair would skip over.  An even count without fields runs in pairs to the end; should rho/u be
+    // asked for after all, materialise_fields() takes the step in between once more.
+    const bool all_pairs = !fuse && nsteps % 2 == 0;
+    bool on_pair = false;
+    if ((nsteps >= 3 || all_pairs) && fused_applies(c)) {
         rc = fused_prepare(c);
         if (rc) return rc;
         if (c->fused_usable) {
-            for (; s + 2 < nsteps; s += 2) {
+            on_pair = all_pairs;
+            for (; s + (all_pairs ? 1 : 2) < nsteps; s += 2) {
                 rc = fused_pair(c, s == 0);
                 if (rc) return rc;
             }
@@ -1625,6 +1640,7 @@ int lbm_step(lbm_ctx* c, int nsteps) {
     c->fields = fuse ? FIELDS_VALID : FIELDS_STALE;
     c->prev_touched = false;
     c->pair_last = false;
+    c->ended_on_pair = on_pair;
     c->fields_wanted = false;
     c->curl_valid = false;
     return LBM_OK;
@@ -1678,6 +1694,7 @@ int lbm_step_frames(lbm_ctx* c, int nframes, int want_curl) {
     c->fields = FIELDS_VALID;
     c->prev_touched = false;
     c->pair_last = false;
+    c->ended_on_pair = false;
     c->fields_wanted = true;     // this caller reads the fields every frame
     c->curl_valid = want_curl != 0;
     return LBM_OK;
@@ -2392,6 +2409,7 @@ int lbm_pair_finish(lbm_ctx* c) {
     c->steps += 2;
     c->fields = FIELDS_STALE;
     c->pair_last = true;   // the previous buffer is two steps old: no rho/u on demand until a single step has run
+    c->ended_on_pair = false;
     c->prev_touched = false;
     c->curl_valid = false;
     c->pair_phase = 0;
@@ -2433,6 +2451,7 @@ int lbm_step_finish(lbm_ctx* c) {
     c->fields = c->scheme == LBM_SCHEME_AB ? FIELDS_STALE : FIELDS_VALID;
     c->prev_touched = false;
     c->pair_last = false;
+    c->ended_on_pair = false;
     c->curl_valid = false;
     c->split_phase = 0;
     return LBM_OK;

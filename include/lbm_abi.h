@@ -91,12 +91,14 @@ typedef struct lbm_opts {
      * it; the CALLER orders the two streams (see cfd_amd/slab.py).  NULL = use `stream`. */
     void*   boundary_stream;
     int32_t slide_chunk;   /* LBM_SCHEME_SLIDE: layers per launch (spare layers = chunk + 2); 0 = library default (32) */
-    /* LBM_SCHEME_AB, undecomposed, row-interleaved layout: lbm_step(ctx, n >= 3) advances TWO time steps per pass
+    /* LBM_SCHEME_AB, undecomposed, row-interleaved layout: lbm_step(ctx, n >= 2) advances TWO time steps per pass
      * over HBM wherever a block of tiles keeps off the domain's walls, obstacles included (k_fused2.h: 76 B x
      * (1 + halo) read + 76 B written per two updates instead of 304 B) and takes the rim -- wall rows and layers --
      * through two ordinary steps via a third population buffer (allocated on first use: +50 % population memory;
      * with obstacles also one 32-bit word per cell).  Results are bit-identical
-     * to single steps; the last step of every call is a single step (its rho/u stay available on demand).
+     * to single steps.  The last step of a call is a single step when n is odd or when the caller read rho/u after its
+     * previous call (that step then writes them); an even n without that runs in pairs to the end, and rho/u of the
+     * last step stay available on demand (at the price of one more step).
      * LBM_TWO_STEP_AUTO = on where it applies. */
     int32_t two_step;      /* LBM_TWO_STEP_* */
     int32_t reserved[2];

@@ -1,5 +1,5 @@
-"""Two steps per pass (cfd_amd/csrc/k_fused2.h, lbm_opts.two_step): lbm_step(ctx, n >= 3) on an A/B context
-advances blocks of plain-fluid tiles by TWO time steps in one kernel and takes the rim (walls, tiles near
+"""Two steps per pass (cfd_amd/csrc/k_fused2.h, lbm_opts.two_step): lbm_step(ctx, n >= 3, or n = 2 when the caller did
+not read rho/u after its previous call) on an A/B context advances blocks of plain-fluid tiles by TWO time steps in one kernel and takes the rim (walls, tiles near
 solids, ragged remainders) through two ordinary steps via a third buffer.  Every cell must come out
 bit-identical to the CPU oracle's single steps (lbm_solver.cu:242-402, 477-494) -- fields, populations and
 frozen solid cells -- for both presets, every compiled kernel variant, any z split, ragged sizes, obstacles,
@@ -41,10 +41,51 @@ def test_fused_empty_box(oracle, lbm, preset, nsteps):
     o.init(); g.init()
     o.step(nsteps); g.step(nsteps)
     same(o, g, f"preset {preset}, {nsteps} steps")
-    if nsteps >= 3:
-        fused_in_use(lbm, g)
-    else:
-        assert g.stats()["fused_cells"] == 0      # nothing prepared for calls that cannot fuse
+    fused_in_use(lbm, g)
+    # the caller has read rho/u now: a call of one or two steps writes them as it goes and cannot fuse
+    g2 = lbm.Solver(W, H, D, preset)
+    g2.init()
+    g2.density()
+    g2.step(2)
+    assert g2.stats()["fused_cells"] == 0         # nothing prepared for calls that cannot fuse
+    g2.close()
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_even_batches_end_on_a_pair(oracle, lbm, preset):
+    """an even lbm_step(n) whose caller did not read rho/u before runs in pairs to the end (no single step behind the
+    last pair); rho/u asked for afterwards are those of the LAST step all the same (one step from the buffer two steps
+    back into the rim's buffer, then the gather), also when a mask change settles them first, when the caller changed
+    the parameters in between, and over several such calls in a row"""
+    import os
+    rows = os.environ.get("LBM_LAYOUT") == str(lbm.LAYOUT_ROWS)
+    W, H, D = 136, 30, 26
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    for s in (o, g):
+        s.init()
+        s.add_solid(50, 8, 9, 12, 7, 6)
+    o.step(6); g.step(6)
+    if rows:
+        st = g.stats()
+        assert st["fused_cells"] > 0
+    o.step(4); g.step(4)                     # a second call straight behind the first: no fields in between
+    for s in (o, g):
+        s.set_params(inlet_velocity=0.05)    # the fields of the last step were made with the OLD parameters
+    same(o, g, f"preset {preset}: two even calls, then the fields")
+    o.step(8); g.step(8)                     # (this call writes rho/u as it goes: the caller read them before)
+    same(o, g, f"preset {preset}: even call after a read")
+    o.step(4); g.step(4)
+    o.step(6); g.step(6)
+    for s in (o, g):
+        s.add_solid(90, 0, 4, 10, 9, 9)      # settles rho/u of the last step with the old mask first
+    np.testing.assert_array_equal(g.density(), o.density())
+    np.testing.assert_array_equal(g.velocity(), o.velocity())
+    o.step(2); g.step(2)
+    same(o, g, f"preset {preset}: after the mask change")
+    o.step(10); g.step(10)
+    g.set_field_window(3, 5)                 # drops the fields; asked for again they come through the same path
+    np.testing.assert_array_equal(g.density(), np.asarray(o.density()).reshape(D, H, W)[3:8].ravel())
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
