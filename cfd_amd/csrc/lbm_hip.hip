@@ -2457,4 +2457,98 @@ int lbm_step_finish(lbm_ctx* c) {
     return LBM_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// stream-ordered flags between ranks (cfd_amd/slab.py: IpcCopyP2P)
+// ------------------------------------------------------------------------------------------
+// A halo transport made of peer copies has no kernels of its own competing with k_fused2 for the CUs (RCCL's send / recv
+// kernel does: profiles/r03_tuning.md section 8), but the two ranks of a link then need another way to tell each other
+// "the data has landed" and "the buffer is free again" in stream order.  The flags a rank waits on live in fine-grained
+// memory of its own GPU that its neighbours map through an IPC handle: the writer's store goes out when its stream gets
+// there, the reader's stream holds a one-lane kernel that polls until the value is reached -- or a time limit passes,
+// so the grid always drains.
+__global__ void k_flag_post(unsigned* flag, unsigned value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_flag_await(const unsigned* flag, unsigned value, unsigned long long ticks, unsigned* timed_out) {
+    // (an earlier wait of this rank gave up: the peer is gone, do not wait again for every exchange still queued)
+    if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(v - value) >= 0) return;
+        if (wall_clock64() - t0 > ticks) {
+            __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+int lbm_flags_create(size_t words, void** d_block, void* ipc_handle) {
+    if (!words || !d_block) return fail(nullptr, LBM_ERR_INVALID, "lbm_flags_create: null argument");
+    *d_block = nullptr;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "include/lbm_abi.h documents a 64-byte handle");
+    // fine-grained device memory: a word a peer stores into is seen by a kernel that is already polling it
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, words * sizeof(uint32_t), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
+    e = hipMemset(p, 0, words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && ipc_handle) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle), p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return fail(nullptr, LBM_ERR_HIP, "lbm_flags_create: %s", hipGetErrorString(e));
+    }
+    *d_block = p;
+    return LBM_OK;
+}
+
+int lbm_flags_destroy(void* d_block) {
+    if (!d_block) return LBM_OK;
+    const hipError_t e = hipFree(d_block);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_destroy: %s", hipGetErrorString(e)); }
+    return LBM_OK;
+}
+
+int lbm_flags_open(const void* ipc_handle, void** d_block) {
+    if (!ipc_handle || !d_block) return fail(nullptr, LBM_ERR_INVALID, "lbm_flags_open: null argument");
+    *d_block = nullptr;
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle, sizeof h);
+    const hipError_t e = hipIpcOpenMemHandle(d_block, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); *d_block = nullptr; return fail(nullptr, LBM_ERR_HIP, "lbm_flags_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
+    return LBM_OK;
+}
+
+int lbm_flags_close(void* d_block) {
+    if (!d_block) return LBM_OK;
+    const hipError_t e = hipIpcCloseMemHandle(d_block);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_close: %s", hipGetErrorString(e)); }
+    return LBM_OK;
+}
+
+int lbm_flag_peek(const uint32_t* d_flag, uint32_t* value) {
+    if (!d_flag || !value) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_peek: null argument");
+    const hipError_t e = hipMemcpy(value, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flag_peek: %s", hipGetErrorString(e)); }
+    return LBM_OK;
+}
+
+int lbm_flag_post(void* stream, uint32_t* d_flag, uint32_t value) {
+    if (!d_flag) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_post: null flag");
+    hipLaunchKernelGGL(k_flag_post, dim3(1), dim3(1), 0, (hipStream_t)stream, d_flag, value);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LBM_OK : fail(nullptr, LBM_ERR_HIP, "lbm_flag_post: %s", hipGetErrorString(e));
+}
+
+int lbm_flag_await(void* stream, const uint32_t* d_flag, uint32_t value, uint32_t timeout_ms, uint32_t* d_timed_out) {
+    if (!d_flag || !d_timed_out) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_await: null argument");
+    if (timeout_ms == 0 || timeout_ms > 600000u) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_await: timeout_ms %u (1 .. 600000)", timeout_ms);
+    hipLaunchKernelGGL(k_flag_await, dim3(1), dim3(1), 0, (hipStream_t)stream, d_flag, value,
+                       (unsigned long long)timeout_ms * 100000ull /* 100 MHz */, d_timed_out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LBM_OK : fail(nullptr, LBM_ERR_HIP, "lbm_flag_await: %s", hipGetErrorString(e));
+}
+
 }  // extern "C"

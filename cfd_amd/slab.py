@@ -296,6 +296,139 @@ class HostStagedP2P(TorchP2P):
             recv.copy_(hr)                             # on the current stream, ahead of the unpack kernels
 
 
+class IpcCopyP2P:
+    """Halo transport without kernels of its own: the sender copies its message straight into the receiver's buffer
+    (mapped through an IPC memory handle; a peer copy over xGMI between GPUs), and the two ranks of a link keep in step
+    through stream-ordered flags in fine-grained device memory that the neighbours map as well (lbm_flags_* /
+    lbm_flag_post / lbm_flag_await, include/lbm_abi.h).  Why: RCCL's send / recv kernel needs CUs, waits for them beside
+    k_fused2 and costs a slab step 10-12 % (profiles/r03_tuning.md section 8); a copy and two one-lane kernels do not.
+
+    register(items) is collective and binds the transport to the PERSISTENT message tensors of a SlabSolver (same list
+    layout as exchange()); any other exchange -- the mask layers, unregistered tensors -- goes through `fallback`
+    (TorchP2P over RCCL, HostStagedP2P under gloo).  Every rank owns the flags it WAITS on: arrived[i] (item i of a
+    neighbour has landed in my recv_i) and free[i] (the receiver of my send_i has consumed it).  Per exchange number q,
+    on torch's current stream, in this order:
+        post   free[i] of src's block = q - 1   everything before this call on the stream has read my receive buffers
+        await  my free[i] >= q - 1              the receiver is done with what I sent last time
+        copy   send_i -> the receiver's recv_i;  post arrived[i] of dst's block = q
+        await  my arrived[i] >= q               my neighbours' messages have landed
+    Every rank posts before it waits, so no cycle of waits exists.  An await gives up after `timeout_ms` and raises the
+    rank's timed-out word instead of hanging the GPU: check timed_out() after a run.  A one-rank ring (dst == me)
+    copies inside the process with the same flags.  Item i of the sender lands in item i of the receiver, as with the
+    ordered send / recv pairs of TorchP2P."""
+
+    LINE = 16                                          # 32-bit words per flag: a 64-byte line each
+
+    def __init__(self, fallback, dist, rank, world, timeout_ms=10000):
+        self.fallback, self.dist, self.rank, self.world = fallback, dist, rank, world
+        self.timeout_ms = timeout_ms
+        self._lib = lbm.load_library()
+        self.seq = 0
+        self.items = None
+        self.remote = []
+        self.block = None                              # my flags (device address)
+        self.peer_block = {}                           # rank -> device address of its flags here
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._lib.lbm_last_error(None).decode()}")
+
+    def _flag(self, rank, item, kind):
+        """device address of a flag in `rank`'s block: kind 0 arrived, 1 free"""
+        base = self.block if rank == self.rank else self.peer_block[rank]
+        return base + 4 * self.LINE * (item * 2 + kind)
+
+    def register(self, items):
+        import ctypes as C
+        from torch.multiprocessing.reductions import reduce_tensor
+        dist = self.dist
+        self.nitems = len(items)
+        blk, handle = C.c_void_p(), C.create_string_buffer(64)
+        self._chk(self._lib.lbm_flags_create(self.LINE * (2 * self.nitems + 1), C.byref(blk), handle), "lbm_flags_create")
+        self.block = blk.value
+        self._timed_out = self.block + 4 * self.LINE * 2 * self.nitems
+        # hand every sender the buffer it writes into, and every neighbour my flags
+        mine = {"flags": handle.raw,
+                "recv": [reduce_tensor(recv) if (src is not None and src != self.rank) else None for _, _, recv, src in items]}
+        everyone = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone[0] = mine
+        peers = {r for _, dst, _, src in items for r in (dst, src) if r is not None and r != self.rank}
+        for r in sorted(peers):
+            p = C.c_void_p()
+            self._chk(self._lib.lbm_flags_open(everyone[r]["flags"], C.byref(p)), "lbm_flags_open")
+            self.peer_block[r] = p.value
+        self.remote = []
+        for i, (_, dst, recv, _) in enumerate(items):
+            if dst is None:
+                self.remote.append(None)
+            elif dst == self.rank:
+                self.remote.append(recv)               # a ring of one: the message comes back to its sender
+            else:
+                fn, args = everyone[dst]["recv"][i]
+                self.remote.append(fn(*args))
+        if self.world > 1:
+            dist.barrier()                             # every handle has been opened while its owner was alive
+        self.items = [(send.data_ptr(), dst, recv.data_ptr(), src) for send, dst, recv, src in items]
+        self.seq = 0
+
+    def _registered(self, items):
+        return self.items is not None and len(items) == len(self.items) and all(
+            (s.data_ptr(), d, r.data_ptr(), c) == reg for (s, d, r, c), reg in zip(items, self.items))
+
+    def exchange(self, items):
+        if not self._registered(items):
+            return ("fallback", self.fallback.exchange(items))
+        lib, stream = self._lib, torch.cuda.current_stream().cuda_stream
+        self.seq = (self.seq + 1) & 0xffffffff
+        q, before = self.seq, (self.seq - 1) & 0xffffffff
+        for i, (_, _, _, src) in enumerate(items):
+            if src is not None:
+                self._chk(lib.lbm_flag_post(stream, self._flag(src, i, 1), before), "lbm_flag_post")
+        for i, (send, dst, _, _) in enumerate(items):
+            if dst is not None:
+                self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 1), before, self.timeout_ms, self._timed_out), "lbm_flag_await")
+                self.remote[i].copy_(send, non_blocking=True)
+                self._chk(lib.lbm_flag_post(stream, self._flag(dst, i, 0), q), "lbm_flag_post")
+        for i, (_, _, _, src) in enumerate(items):
+            if src is not None:
+                self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 0), q, self.timeout_ms, self._timed_out), "lbm_flag_await")
+        return ("ipc", None)
+
+    def wait(self, handle):
+        kind, h = handle
+        if kind == "fallback":
+            self.fallback.wait(h)
+
+    def timed_out(self):
+        """an await of THIS rank gave up (blocking read of the word the device sets)"""
+        import ctypes as C
+        if self.block is None:
+            return False
+        v = C.c_uint32(0)
+        self._chk(self._lib.lbm_flag_peek(self._timed_out, C.byref(v)), "lbm_flag_peek")
+        return v.value != 0
+
+    def close(self):
+        """collective when world > 1: nobody unmaps a neighbour's flags while that neighbour may still post into them"""
+        if self.block is None:
+            return
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.remote = []
+        self.items = None
+        for p in self.peer_block.values():
+            self._lib.lbm_flags_close(p)
+        self.peer_block = {}
+        if self.world > 1:
+            self.dist.barrier()
+        self._lib.lbm_flags_destroy(self.block)
+        self.block = None
+
+
 class SlabSolver:
     """One rank's share of a W x H x depth_global domain.  Mirrors lbm_solver's surface for the
     calls that make sense per slab (init, step, set_solid with the slab's own layers, read-back)."""
@@ -308,6 +441,8 @@ class SlabSolver:
         self.send = [engine.new_message(), engine.new_message()]
         self.recv = [engine.new_message(), engine.new_message()]
         self.use_pairs = os.environ.get("LBM_SLAB_PAIRS", "1") != "0"
+        if hasattr(transport, "register"):             # (collective: every rank builds its SlabSolver at the same point)
+            transport.register(self._items(self.send, self.recv))
 
     # message leaving through our TOP face goes to `up` and lands on its BOTTOM ghost, and vice versa
     def _items(self, send, recv):

@@ -1,0 +1,9 @@
+#!/bin/bash
+# the peer-copy transport between two / three processes that share the GPU
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+timeout -k 10 400 python3 -u -m pytest tests/test_two_ranks_one_gpu.py -x -v -k peer_copy --timeout 180 --timeout-method thread > gpurun_out/r3_ipc_test.log 2>&1
+rc=$?
+tail -n 40 gpurun_out/r3_ipc_test.log
+exit $rc
