@@ -2484,47 +2484,56 @@ __global__ void k_flag_await(const unsigned* flag, unsigned value, unsigned long
     }
 }
 
-int lbm_flags_create(size_t words, void** d_block, void* ipc_handle) {
-    if (!words || !d_block) return fail(nullptr, LBM_ERR_INVALID, "lbm_flags_create: null argument");
-    *d_block = nullptr;
+int lbm_ipc_alloc(size_t bytes, int fine_grained, void** d_ptr, void* ipc_handle) {
+    if (!bytes || !d_ptr) return fail(nullptr, LBM_ERR_INVALID, "lbm_ipc_alloc: null argument");
+    *d_ptr = nullptr;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "include/lbm_abi.h documents a 64-byte handle");
-    // fine-grained device memory: a word a peer stores into is seen by a kernel that is already polling it
+    // fine-grained device memory (the flags): a word a peer stores into is seen by a kernel that is already polling it.
+    // The message buffers are ordinary device memory: their reader starts after the flag said the data has landed.
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, words * sizeof(uint32_t), hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
-    e = hipMemset(p, 0, words * sizeof(uint32_t));
+    hipError_t e = fine_grained ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_alloc: %s", hipGetErrorString(e)); }
+    e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && ipc_handle) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle), p);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(p);
-        return fail(nullptr, LBM_ERR_HIP, "lbm_flags_create: %s", hipGetErrorString(e));
+        return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_alloc: %s", hipGetErrorString(e));
     }
-    *d_block = p;
+    *d_ptr = p;
     return LBM_OK;
 }
 
-int lbm_flags_destroy(void* d_block) {
-    if (!d_block) return LBM_OK;
-    const hipError_t e = hipFree(d_block);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_destroy: %s", hipGetErrorString(e)); }
+int lbm_ipc_free(void* d_ptr) {
+    if (!d_ptr) return LBM_OK;
+    const hipError_t e = hipFree(d_ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_free: %s", hipGetErrorString(e)); }
     return LBM_OK;
 }
 
-int lbm_flags_open(const void* ipc_handle, void** d_block) {
-    if (!ipc_handle || !d_block) return fail(nullptr, LBM_ERR_INVALID, "lbm_flags_open: null argument");
-    *d_block = nullptr;
+int lbm_ipc_open(const void* ipc_handle, void** d_ptr) {
+    if (!ipc_handle || !d_ptr) return fail(nullptr, LBM_ERR_INVALID, "lbm_ipc_open: null argument");
+    *d_ptr = nullptr;
     hipIpcMemHandle_t h;
     memcpy(&h, ipc_handle, sizeof h);
-    const hipError_t e = hipIpcOpenMemHandle(d_block, h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) { (void)hipGetLastError(); *d_block = nullptr; return fail(nullptr, LBM_ERR_HIP, "lbm_flags_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
+    const hipError_t e = hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); *d_ptr = nullptr; return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
     return LBM_OK;
 }
 
-int lbm_flags_close(void* d_block) {
-    if (!d_block) return LBM_OK;
-    const hipError_t e = hipIpcCloseMemHandle(d_block);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_flags_close: %s", hipGetErrorString(e)); }
+int lbm_ipc_close(void* d_ptr) {
+    if (!d_ptr) return LBM_OK;
+    const hipError_t e = hipIpcCloseMemHandle(d_ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_close: %s", hipGetErrorString(e)); }
+    return LBM_OK;
+}
+
+int lbm_ipc_copy(void* stream, void* d_dst, const void* d_src, size_t bytes) {
+    if (!d_dst || !d_src) return fail(nullptr, LBM_ERR_INVALID, "lbm_ipc_copy: null argument");
+    if (!bytes) return LBM_OK;
+    const hipError_t e = hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_copy: %s", hipGetErrorString(e)); }
     return LBM_OK;
 }
 

@@ -108,10 +108,11 @@ SIGNATURES = {
     "lbm_pair_boundary_second": ([_ctx, C.c_void_p, C.c_void_p], C.c_int),
     "lbm_pair_finish": ([_ctx], C.c_int),
     "lbm_fused_chain_stamps": ([_ctx, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_int)], C.c_int),
-    "lbm_flags_create": ([C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p], C.c_int),
-    "lbm_flags_destroy": ([C.c_void_p], C.c_int),
-    "lbm_flags_open": ([C.c_void_p, C.POINTER(C.c_void_p)], C.c_int),
-    "lbm_flags_close": ([C.c_void_p], C.c_int),
+    "lbm_ipc_alloc": ([C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_void_p], C.c_int),
+    "lbm_ipc_free": ([C.c_void_p], C.c_int),
+    "lbm_ipc_open": ([C.c_void_p, C.POINTER(C.c_void_p)], C.c_int),
+    "lbm_ipc_close": ([C.c_void_p], C.c_int),
+    "lbm_ipc_copy": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t], C.c_int),
     "lbm_flag_peek": ([C.c_void_p, C.POINTER(C.c_uint32)], C.c_int),
     "lbm_flag_post": ([C.c_void_p, C.c_void_p, C.c_uint32], C.c_int),
     "lbm_flag_await": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int),

@@ -296,18 +296,27 @@ class HostStagedP2P(TorchP2P):
             recv.copy_(hr)                             # on the current stream, ahead of the unpack kernels
 
 
+class _DevicePointer:
+    """a raw device allocation as torch sees it (torch.as_tensor reads __cuda_array_interface__)"""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
 class IpcCopyP2P:
     """Halo transport without kernels of its own: the sender copies its message straight into the receiver's buffer
     (mapped through an IPC memory handle; a peer copy over xGMI between GPUs), and the two ranks of a link keep in step
-    through stream-ordered flags in fine-grained device memory that the neighbours map as well (lbm_flags_* /
+    through stream-ordered flags in fine-grained device memory that the neighbours map as well (lbm_ipc_* /
     lbm_flag_post / lbm_flag_await, include/lbm_abi.h).  Why: RCCL's send / recv kernel needs CUs, waits for them beside
     k_fused2 and costs a slab step 10-12 % (profiles/r03_tuning.md section 8); a copy and two one-lane kernels do not.
 
-    register(items) is collective and binds the transport to the PERSISTENT message tensors of a SlabSolver (same list
-    layout as exchange()); any other exchange -- the mask layers, unregistered tensors -- goes through `fallback`
-    (TorchP2P over RCCL, HostStagedP2P under gloo).  Every rank owns the flags it WAITS on: arrived[i] (item i of a
-    neighbour has landed in my recv_i) and free[i] (the receiver of my send_i has consumed it).  Per exchange number q,
-    on torch's current stream, in this order:
+    bind(links, nfloats, device) is collective and all-or-nothing: it allocates this rank's receive buffers (one per item
+    with a source) and flags, trades the IPC handles, maps the neighbours' and returns the receive buffers as torch
+    tensors for SlabSolver to use -- or None on EVERY rank if any step failed on any rank; the transport then passes
+    everything to `fallback` (TorchP2P over RCCL, HostStagedP2P under gloo), as it always does for exchanges into other
+    tensors (the mask layers).  Every rank owns the flags it WAITS on: arrived[i] (item i of a neighbour has landed in my
+    recv_i) and free[i] (the receiver of my send_i has consumed it).  Per exchange number q, on torch's current stream,
+    in this order:
         post   free[i] of src's block = q - 1   everything before this call on the stream has read my receive buffers
         await  my free[i] >= q - 1              the receiver is done with what I sent last time
         copy   send_i -> the receiver's recv_i;  post arrived[i] of dst's block = q
@@ -324,10 +333,13 @@ class IpcCopyP2P:
         self.timeout_ms = timeout_ms
         self._lib = lbm.load_library()
         self.seq = 0
-        self.items = None
-        self.remote = []
+        self.links = None                              # [(dst, src)] per item once bound
+        self.recv, self._recv_ptr = [], []             # my receive buffers: torch views, device addresses
+        self.remote = []                               # where my item i goes: device address at dst (or my own)
+        self._opened = []
         self.block = None                              # my flags (device address)
         self.peer_block = {}                           # rank -> device address of its flags here
+        self.error = None
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -338,61 +350,85 @@ class IpcCopyP2P:
         base = self.block if rank == self.rank else self.peer_block[rank]
         return base + 4 * self.LINE * (item * 2 + kind)
 
-    def register(self, items):
-        import ctypes as C
-        from torch.multiprocessing.reductions import reduce_tensor
-        dist = self.dist
-        self.nitems = len(items)
-        blk, handle = C.c_void_p(), C.create_string_buffer(64)
-        self._chk(self._lib.lbm_flags_create(self.LINE * (2 * self.nitems + 1), C.byref(blk), handle), "lbm_flags_create")
-        self.block = blk.value
-        self._timed_out = self.block + 4 * self.LINE * 2 * self.nitems
-        # hand every sender the buffer it writes into, and every neighbour my flags
-        mine = {"flags": handle.raw,
-                "recv": [reduce_tensor(recv) if (src is not None and src != self.rank) else None for _, _, recv, src in items]}
+    def _gather(self, mine):
+        if self.world == 1:
+            return [mine]
         everyone = [None] * self.world
-        if self.world > 1:
-            dist.all_gather_object(everyone, mine)
-        else:
-            everyone[0] = mine
-        peers = {r for _, dst, _, src in items for r in (dst, src) if r is not None and r != self.rank}
-        for r in sorted(peers):
-            p = C.c_void_p()
-            self._chk(self._lib.lbm_flags_open(everyone[r]["flags"], C.byref(p)), "lbm_flags_open")
-            self.peer_block[r] = p.value
-        self.remote = []
-        for i, (_, dst, recv, _) in enumerate(items):
-            if dst is None:
-                self.remote.append(None)
-            elif dst == self.rank:
-                self.remote.append(recv)               # a ring of one: the message comes back to its sender
-            else:
-                fn, args = everyone[dst]["recv"][i]
-                self.remote.append(fn(*args))
-        if self.world > 1:
-            dist.barrier()                             # every handle has been opened while its owner was alive
-        self.items = [(send.data_ptr(), dst, recv.data_ptr(), src) for send, dst, recv, src in items]
-        self.seq = 0
+        self.dist.all_gather_object(everyone, mine)
+        return everyone
 
-    def _registered(self, items):
-        return self.items is not None and len(items) == len(self.items) and all(
-            (s.data_ptr(), d, r.data_ptr(), c) == reg for (s, d, r, c), reg in zip(items, self.items))
+    def bind(self, links, nfloats, device):
+        import ctypes as C
+        lib = self._lib
+        n = len(links)
+        self.nbytes = 4 * nfloats
+        mine = None
+        try:                                           # (a rank that fails still takes part in every collective below)
+            with torch.cuda.device(device):
+                blk, handle = C.c_void_p(), C.create_string_buffer(64)
+                self._chk(lib.lbm_ipc_alloc(4 * self.LINE * (2 * n + 1), 1, C.byref(blk), handle), "lbm_ipc_alloc (flags)")
+                self.block = blk.value
+                self._timed_out = self.block + 4 * self.LINE * 2 * n
+                mine = {"flags": handle.raw, "recv": [None] * n}
+                self._recv_ptr = [None] * n
+                for i, (_, src) in enumerate(links):
+                    if src is not None:
+                        p, h = C.c_void_p(), C.create_string_buffer(64)
+                        self._chk(lib.lbm_ipc_alloc(self.nbytes, 0, C.byref(p), h), "lbm_ipc_alloc (message)")
+                        self._recv_ptr[i] = p.value
+                        mine["recv"][i] = h.raw
+        except Exception as e:                         # noqa: BLE001
+            self.error, mine = e, None
+        everyone = self._gather(mine)
+        ok = all(x is not None for x in everyone)
+        if ok:
+            try:
+                with torch.cuda.device(device):
+                    for r in sorted({r for pair in links for r in pair if r is not None and r != self.rank}):
+                        p = C.c_void_p()
+                        self._chk(lib.lbm_ipc_open(everyone[r]["flags"], C.byref(p)), "lbm_ipc_open (flags)")
+                        self.peer_block[r] = p.value
+                        self._opened.append(p.value)
+                    self.remote = [None] * n
+                    for i, (dst, _) in enumerate(links):
+                        if dst == self.rank:
+                            self.remote[i] = self._recv_ptr[i]     # a ring of one: the message comes back to its sender
+                        elif dst is not None:
+                            p = C.c_void_p()
+                            self._chk(lib.lbm_ipc_open(everyone[dst]["recv"][i], C.byref(p)), "lbm_ipc_open (message)")
+                            self.remote[i] = p.value
+                            self._opened.append(p.value)
+            except Exception as e:                     # noqa: BLE001
+                self.error, ok = e, False
+        ok = all(self._gather(bool(ok)))               # (also: every handle has been opened while its owner was alive)
+        if not ok:
+            self._release()
+            return None
+        self.links = list(links)
+        self.recv = [None if p is None else torch.as_tensor(_DevicePointer(p, nfloats), device=device) for p in self._recv_ptr]
+        self.seq = 0
+        return self.recv
+
+    def _bound(self, items):
+        return self.links is not None and len(items) == len(self.links) and all(
+            (d, c) == link and (c is None or r.data_ptr() == p) and (d is None or s.numel() * s.element_size() == self.nbytes)
+            for (s, d, r, c), link, p in zip(items, self.links, self._recv_ptr))
 
     def exchange(self, items):
-        if not self._registered(items):
+        if not self._bound(items):
             return ("fallback", self.fallback.exchange(items))
         lib, stream = self._lib, torch.cuda.current_stream().cuda_stream
         self.seq = (self.seq + 1) & 0xffffffff
         q, before = self.seq, (self.seq - 1) & 0xffffffff
-        for i, (_, _, _, src) in enumerate(items):
+        for i, (_, src) in enumerate(self.links):
             if src is not None:
                 self._chk(lib.lbm_flag_post(stream, self._flag(src, i, 1), before), "lbm_flag_post")
-        for i, (send, dst, _, _) in enumerate(items):
+        for i, (dst, _) in enumerate(self.links):
             if dst is not None:
                 self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 1), before, self.timeout_ms, self._timed_out), "lbm_flag_await")
-                self.remote[i].copy_(send, non_blocking=True)
+                self._chk(lib.lbm_ipc_copy(stream, self.remote[i], items[i][0].data_ptr(), self.nbytes), "lbm_ipc_copy")
                 self._chk(lib.lbm_flag_post(stream, self._flag(dst, i, 0), q), "lbm_flag_post")
-        for i, (_, _, _, src) in enumerate(items):
+        for i, (_, src) in enumerate(self.links):
             if src is not None:
                 self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 0), q, self.timeout_ms, self._timed_out), "lbm_flag_await")
         return ("ipc", None)
@@ -401,6 +437,29 @@ class IpcCopyP2P:
         kind, h = handle
         if kind == "fallback":
             self.fallback.wait(h)
+
+    def verify(self, rounds=3):
+        """collective: known patterns through every link, `rounds` times; True on every rank only if every message
+        arrived intact on every rank and no wait ran into its time limit"""
+        if self.links is None:
+            return False
+        ok = True
+        try:
+            dev = next(t for t in self.recv if t is not None).device
+            send = [torch.empty(self.nbytes // 4, dtype=torch.float32, device=dev) for _ in self.links]
+            for k in range(rounds):
+                for i, (dst, _) in enumerate(self.links):
+                    if dst is not None:
+                        send[i].fill_(float(1 + self.rank * 64 + i * 8 + k))
+                self.wait(self.exchange([(send[i], d, self.recv[i] if c is not None else send[i], c) for i, (d, c) in enumerate(self.links)]))
+                for i, (_, src) in enumerate(self.links):
+                    if src is not None:
+                        ok = ok and bool((self.recv[i] == float(1 + src * 64 + i * 8 + k)).all())
+            torch.cuda.synchronize()
+            ok = ok and not self.timed_out()
+        except Exception as e:                         # noqa: BLE001
+            self.error, ok = e, False
+        return all(self._gather(bool(ok)))
 
     def timed_out(self):
         """an await of THIS rank gave up (blocking read of the word the device sets)"""
@@ -411,22 +470,29 @@ class IpcCopyP2P:
         self._chk(self._lib.lbm_flag_peek(self._timed_out, C.byref(v)), "lbm_flag_peek")
         return v.value != 0
 
-    def close(self):
-        """collective when world > 1: nobody unmaps a neighbour's flags while that neighbour may still post into them"""
-        if self.block is None:
-            return
+    def _release(self):
+        """collective when world > 1: nobody unmaps or frees memory a neighbour may still write into"""
         torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
-        self.remote = []
-        self.items = None
-        for p in self.peer_block.values():
-            self._lib.lbm_flags_close(p)
-        self.peer_block = {}
+        self.links, self.recv, self.remote = None, [], []
+        for p in self._opened:
+            self._lib.lbm_ipc_close(p)
+        self._opened, self.peer_block = [], {}
         if self.world > 1:
             self.dist.barrier()
-        self._lib.lbm_flags_destroy(self.block)
+        for p in self._recv_ptr:
+            if p is not None:
+                self._lib.lbm_ipc_free(p)
+        self._recv_ptr = []
+        if self.block is not None:
+            self._lib.lbm_ipc_free(self.block)
         self.block = None
+
+    def close(self):
+        """collective; the tensors bind() returned are gone afterwards"""
+        if self.block is not None or self._opened or self._recv_ptr:
+            self._release()
 
 
 class SlabSolver:
@@ -441,8 +507,13 @@ class SlabSolver:
         self.send = [engine.new_message(), engine.new_message()]
         self.recv = [engine.new_message(), engine.new_message()]
         self.use_pairs = os.environ.get("LBM_SLAB_PAIRS", "1") != "0"
-        if hasattr(transport, "register"):             # (collective: every rank builds its SlabSolver at the same point)
-            transport.register(self._items(self.send, self.recv))
+        if hasattr(transport, "bind"):                 # (collective: every rank builds its SlabSolver at the same point)
+            # a transport that writes into its neighbours' memory brings the receive buffers itself (same order as _items)
+            got = transport.bind([(self.up, self.down), (self.down, self.up)], engine.message_floats(), engine.device)
+            if got is not None:
+                for side, t in ((SIDE_BOTTOM, got[0]), (SIDE_TOP, got[1])):
+                    if t is not None:
+                        self.recv[side] = t
 
     # message leaving through our TOP face goes to `up` and lands on its BOTTOM ghost, and vice versa
     def _items(self, send, recv):

@@ -336,20 +336,23 @@ int lbm_pair_finish(lbm_ctx* ctx);
  * evenly the block chains of a launch end. */
 int lbm_fused_chain_stamps(lbm_ctx* ctx, uint64_t* stamps, size_t n, int* nworkgroups);
 
-/* Stream-ordered flags between the ranks of a halo link (no counterpart in the reference, which has one device): what
- * a transport made of peer copies needs in place of RCCL's own handshake (cfd_amd/slab.py IpcCopyP2P).  The flags are
- * 32-bit words in fine-grained memory of the current device.  lbm_flags_create allocates `words` of them, zeroed, and
- * (ipc_handle != NULL) writes the 64-byte IPC handle other processes open the block with: lbm_flags_open /
- * lbm_flags_close there, lbm_flags_destroy in the owner.  lbm_flag_post stores `value` into a flag -- its own or a
- * neighbour's -- when `stream` (a hipStream_t) gets there; lbm_flag_await holds `stream` until the flag has reached
- * `value` (compared as a wrapping 32-bit sequence number), or until timeout_ms have passed: then it sets *d_timed_out
- * (another word of the rank's own block) to 1 and lets the stream go on, so a lost peer ends in an error the host can
- * read (lbm_flag_peek, blocking), not in a hung GPU; later waits that find the word set return at once.  No context
- * argument: errors are reported through lbm_last_error(NULL). */
-int lbm_flags_create(size_t words, void** d_block, void* ipc_handle);
-int lbm_flags_destroy(void* d_block);
-int lbm_flags_open(const void* ipc_handle, void** d_block);
-int lbm_flags_close(void* d_block);
+/* A halo link between two processes without RCCL (no counterpart in the reference, which has one device): what a
+ * transport made of peer copies needs (cfd_amd/slab.py IpcCopyP2P).
+ * lbm_ipc_alloc: `bytes` of zeroed memory on the current device -- fine-grained for flags, ordinary for message
+ * buffers -- and (ipc_handle != NULL) the 64-byte IPC handle other processes map it with: lbm_ipc_open / lbm_ipc_close
+ * there, lbm_ipc_free in the owner.  lbm_ipc_copy: an asynchronous device-to-device copy on `stream` (a hipStream_t),
+ * e.g. into a neighbour's mapped buffer (a peer copy between GPUs).
+ * Flags are 32-bit words of such a fine-grained block.  lbm_flag_post stores `value` into a flag -- its own or a
+ * neighbour's -- when `stream` gets there; lbm_flag_await holds `stream` until the flag has reached `value` (compared as
+ * a wrapping 32-bit sequence number), or until timeout_ms have passed: then it sets *d_timed_out (another word of the
+ * rank's own block) to 1 and lets the stream go on, so a lost peer ends in an error the host can read (lbm_flag_peek,
+ * blocking), not in a hung GPU; later waits that find the word set return at once.  No context argument: errors are
+ * reported through lbm_last_error(NULL). */
+int lbm_ipc_alloc(size_t bytes, int fine_grained, void** d_ptr, void* ipc_handle);
+int lbm_ipc_free(void* d_ptr);
+int lbm_ipc_open(const void* ipc_handle, void** d_ptr);
+int lbm_ipc_close(void* d_ptr);
+int lbm_ipc_copy(void* stream, void* d_dst, const void* d_src, size_t bytes);
 int lbm_flag_post(void* stream, uint32_t* d_flag, uint32_t value);
 int lbm_flag_await(void* stream, const uint32_t* d_flag, uint32_t value, uint32_t timeout_ms, uint32_t* d_timed_out);
 int lbm_flag_peek(const uint32_t* d_flag, uint32_t* value);

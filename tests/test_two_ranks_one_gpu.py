@@ -34,6 +34,9 @@ def _rank(rank, world, port, preset, W, H, splits, steps, mask, params, out, tra
         if transport == "ipc":
             t = slab.IpcCopyP2P(t, dist, rank, world, timeout_ms=5000)
         drv = slab.SlabSolver(e, preset, world, rank, t)
+        if transport == "ipc":
+            assert t.links is not None, f"bind failed: {t.error}"
+            assert t.verify(), f"verify failed: {t.error}"
         drv.exchange_mask()
         drv.exchange_populations()
         for n in steps:
