@@ -58,6 +58,9 @@ BYTES_PER_CELL = 152           # 19 populations x 4 B x (r
 # under-resolved and blows up after about 700 steps (the CPU oracle does the same), which no benchmark
 # should time; at 1.8 / 1.9 and U = 0.08 it is stable (checked to 30 000 steps on the GPU).  The
 # wind-tunnel configurations keep the reference's defaults (lbm_solver.cuh:9-15).
+# halo transport of the slab path: "rccl" or "ipc" (run_slabs)
+TRANSPORT = os.environ.get("BENCH_TRANSPORT", "ipc")
+TRANSPORT_TEXT = {"rccl": "RCCL send / recv", "ipc": "peer copies into IPC-mapped buffers, flags in fine-grained device memory"}
 CAVITY_PARAMS = dict(inlet_velocity=0.08, omega_shear=1.8, omega_bulk=1.9)
 CAR = os.path.join(ROOT, "tests", "golden", "car_like.obj")
 
@@ -463,29 +466,65 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
             # the in-place schemes write rho/u of the field window in every split step: keep it small
             solver.set_field_window(0, min(4, D))
         staged = world > 1 and dist.get_backend() == "gloo"
-        drv = slab.SlabSolver(eng, preset, world, rank, slab.HostStagedP2P() if staged else slab.TorchP2P())
-        try:
-            solver.init()
-            if params is not None:
-                solver.set_params(**params)
-            elif preset == lbm.PRESET_CAVITY:
-                solver.set_params(**CAVITY_PARAMS)
-            if obstacle:
-                solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
-        except Exception as e:
-            err = e
-        all_ranks_ok(dist, err is None, f"slab initialisation ({err})")
-        drv.exchange_mask()
-        drv.exchange_populations()
-        drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
+        base = slab.HostStagedP2P() if staged else slab.TorchP2P()
+        # BENCH_TRANSPORT / --transport: "rccl" = RCCL send / recv (through the host under BENCH_BACKEND=gloo), "ipc" =
+        # peer copies into the neighbours' IPC-mapped buffers (cfd_amd/slab.py IpcCopyP2P).  The peer copies are taken
+        # only if every rank could map its neighbours' memory AND known patterns came through every link intact;
+        # otherwise every rank goes on with RCCL, and the record says which transport ran and why.
+        ipc, transport, why = None, "rccl", None
+        if TRANSPORT == "ipc":
+            ipc = slab.IpcCopyP2P(base, dist, rank, world)
+        drv = slab.SlabSolver(eng, preset, world, rank, ipc if ipc is not None else base)
+        if ipc is not None:
+            if ipc.links is None:
+                why = f"bind failed ({ipc.error})"
+            elif not ipc.verify():
+                why = f"verification failed ({ipc.error})"
+            if why is None:
+                transport = "ipc"
+            else:
+                ipc.close()
+                ipc, drv.t = None, base
+                drv.recv = [eng.new_message(), eng.new_message()]
 
         def fence():
             dist.barrier()
             torch.cuda.synchronize()
 
-        # (at least 97 steps = 48 pairs: k_fused2 has then settled on the form of its first-step loads, see run_single;
-        # the same count on every rank: a step is a collective)
-        drv.step(max(warmup, 97))
+        def prepare():
+            nonlocal err
+            try:
+                solver.init()
+                if params is not None:
+                    solver.set_params(**params)
+                elif preset == lbm.PRESET_CAVITY:
+                    solver.set_params(**CAVITY_PARAMS)
+                if obstacle:
+                    solver.load_mesh(CAR)   # device voxeliser: every slab casts the rays of its own layers
+            except Exception as e:
+                err = e
+            all_ranks_ok(dist, err is None, f"slab initialisation ({err})")
+            drv.exchange_mask()
+            drv.exchange_populations()
+            drv.autotune_streams()      # untimed: picks streams that land on distinct hardware queues
+            # (at least 97 steps = 48 pairs: k_fused2 has then settled on the form of its first-step loads, see run_single;
+            # the same count on every rank: a step is a collective)
+            drv.step(max(warmup, 97))
+
+        def any_rank_timed_out():
+            torch.cuda.synchronize()
+            t = torch.tensor([1 if ipc.timed_out() else 0], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t[0]) != 0
+
+        prepare()
+        if ipc is not None and any_rank_timed_out():
+            # a wait for a neighbour's flag gave up during the warm-up: start over on RCCL
+            transport, why = "rccl", "a flag wait ran into its time limit during the warm-up"
+            ipc.close()
+            ipc, drv.t = None, base
+            drv.recv = [eng.new_message(), eng.new_message()]
+            prepare()
         n, dt, dev_ms, st = timed_steps(solver, drv.step, steps, min_seconds, fence,
                                         agree=lambda k: agree_steps(dist, k, "cuda"))
         tmax = torch.tensor([dt, dev_ms], dtype=torch.float64, device="cuda")
@@ -499,7 +538,8 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
         dist.all_reduce(finite, op=dist.ReduceOp.MIN)
         res = {"cells_per_gpu": W * H * D, "fluid_cells_per_gpu": fluid, "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
                "mlups": round(W * H * (Dg if not rehearse else D) * n / dt / 1e6, 1), "state_finite": bool(int(finite[0])),
-               "rccl_ranks": world, "slab_layers": D, "slab_z0": z0, "slab_ranges": [list(x) for x in ranges],
+               "rccl_ranks": world, "transport": TRANSPORT_TEXT[transport] + (f" (peer copies not taken: {why})" if why else ""),
+               "slab_layers": D, "slab_z0": z0, "slab_ranges": [list(x) for x in ranges],
                "halo_bytes_per_step_per_gpu": 4 * eng.message_floats() * ((drv.up is not None) + (drv.down is not None)),
                "roofline": roofline_of(st, dev_ms, n, fluid, kernel="k_aa_step" if scheme == lbm.SCHEME_AA else "k_stream_collide")}
         res["two_steps_per_pass"] = res["roofline"]["kernel"] == "k_fused2"
@@ -524,8 +564,15 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
             res["per_rank_ms_no_exchange"] = [round(float(x), 5) for x in own]
             res["ms_per_step_no_exchange"] = round(float(own.max()), 5)
             res["exposed_comm_ms_per_step"] = round(max(0.0, dt / n * 1e3 - float(own.max())), 5)
+        if ipc is not None and any_rank_timed_out():
+            raise RuntimeError("a wait for a neighbour's flag ran into its time limit during the timed region (BENCH_TRANSPORT=rccl avoids the peer copies)")
         return res
     finally:
+        if ipc is not None:
+            try:
+                ipc.close()
+            except Exception as e:                  # noqa: BLE001
+                log("[bench] closing the peer-copy transport:", e)
         solver.close()
 
 
@@ -597,11 +644,17 @@ def main():
     ap.add_argument("--slab-index", type=int, default=None,
                     help="with --rehearse-slab: rehearse slab R of --slabs (default 8) of the configuration's global domain")
     ap.add_argument("--slabs", type=int, default=8)
+    ap.add_argument("--transport", choices=["rccl", "ipc"], default=None,
+                    help="halo transport of the slab path (default: BENCH_TRANSPORT, else ipc = peer copies with RCCL as the fallback, see run_slabs)")
     ap.add_argument("--no-balance", action="store_true", help="strong scaling: keep the even split of the depth (no cost-balanced slabs)")
     ap.add_argument("--no-rehearsal-8", action="store_true", help="N = 1: skip the eight 64-layer slab rehearsals of `strong_scaling`")
     ap.add_argument("--dry-run-launcher", action="store_true", help="CPU test of the N > 1 launcher: gloo rendezvous only")
     args = ap.parse_args()
 
+    global TRANSPORT
+    if args.transport:
+        TRANSPORT = args.transport
+        os.environ["BENCH_TRANSPORT"] = args.transport      # (the ranks self_launch() starts read it)
     in_dist = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_dist:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))

@@ -2484,6 +2484,31 @@ __global__ void k_flag_await(const unsigned* flag, unsigned value, unsigned long
     }
 }
 
+// several posts and several waits in one launch: the posts first (see IpcCopyP2P: every rank posts before it waits)
+struct FlagOps {
+    unsigned* post[LBM_FLAG_OPS_MAX];
+    const unsigned* wait[LBM_FLAG_OPS_MAX];
+    unsigned post_value[LBM_FLAG_OPS_MAX], wait_value[LBM_FLAG_OPS_MAX];
+    int nposts, nwaits;
+};
+__global__ void k_flag_sync(FlagOps ops, unsigned long long ticks, unsigned* timed_out) {
+    for (int i = 0; i < ops.nposts; i++) __hip_atomic_store(ops.post[i], ops.post_value[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ops.nwaits == 0) return;
+    if (__hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < ops.nwaits; i++) {
+        for (;;) {
+            const unsigned v = __hip_atomic_load(ops.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - ops.wait_value[i]) >= 0) break;
+            if (wall_clock64() - t0 > ticks) {
+                __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+
 int lbm_ipc_alloc(size_t bytes, int fine_grained, void** d_ptr, void* ipc_handle) {
     if (!bytes || !d_ptr) return fail(nullptr, LBM_ERR_INVALID, "lbm_ipc_alloc: null argument");
     *d_ptr = nullptr;
@@ -2535,6 +2560,30 @@ int lbm_ipc_copy(void* stream, void* d_dst, const void* d_src, size_t bytes) {
     const hipError_t e = hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, LBM_ERR_HIP, "lbm_ipc_copy: %s", hipGetErrorString(e)); }
     return LBM_OK;
+}
+
+int lbm_flag_sync(void* stream, uint32_t* const* d_post, const uint32_t* post_values, int nposts,
+                  const uint32_t* const* d_wait, const uint32_t* wait_values, int nwaits, uint32_t timeout_ms, uint32_t* d_timed_out) {
+    if (nposts < 0 || nposts > LBM_FLAG_OPS_MAX || nwaits < 0 || nwaits > LBM_FLAG_OPS_MAX)
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_sync: %d posts, %d waits (0 .. %d each)", nposts, nwaits, LBM_FLAG_OPS_MAX);
+    if ((nposts && (!d_post || !post_values)) || (nwaits && (!d_wait || !wait_values || !d_timed_out)))
+        return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_sync: null argument");
+    if (nwaits && (timeout_ms == 0 || timeout_ms > 600000u)) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_sync: timeout_ms %u (1 .. 600000)", timeout_ms);
+    if (nposts + nwaits == 0) return LBM_OK;
+    FlagOps ops;
+    memset(&ops, 0, sizeof ops);
+    ops.nposts = nposts; ops.nwaits = nwaits;
+    for (int i = 0; i < nposts; i++) {
+        if (!d_post[i]) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_sync: null flag");
+        ops.post[i] = d_post[i]; ops.post_value[i] = post_values[i];
+    }
+    for (int i = 0; i < nwaits; i++) {
+        if (!d_wait[i]) return fail(nullptr, LBM_ERR_INVALID, "lbm_flag_sync: null flag");
+        ops.wait[i] = d_wait[i]; ops.wait_value[i] = wait_values[i];
+    }
+    hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(1), 0, (hipStream_t)stream, ops, (unsigned long long)timeout_ms * 100000ull, d_timed_out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LBM_OK : fail(nullptr, LBM_ERR_HIP, "lbm_flag_sync: %s", hipGetErrorString(e));
 }
 
 int lbm_flag_peek(const uint32_t* d_flag, uint32_t* value) {

@@ -113,6 +113,8 @@ SIGNATURES = {
     "lbm_ipc_open": ([C.c_void_p, C.POINTER(C.c_void_p)], C.c_int),
     "lbm_ipc_close": ([C.c_void_p], C.c_int),
     "lbm_ipc_copy": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t], C.c_int),
+    "lbm_flag_sync": ([C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int,
+                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int, C.c_uint32, C.c_void_p], C.c_int),
     "lbm_flag_peek": ([C.c_void_p, C.POINTER(C.c_uint32)], C.c_int),
     "lbm_flag_post": ([C.c_void_p, C.c_void_p, C.c_uint32], C.c_int),
     "lbm_flag_await": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p], C.c_int),

@@ -420,18 +420,24 @@ class IpcCopyP2P:
         lib, stream = self._lib, torch.cuda.current_stream().cuda_stream
         self.seq = (self.seq + 1) & 0xffffffff
         q, before = self.seq, (self.seq - 1) & 0xffffffff
-        for i, (_, src) in enumerate(self.links):
-            if src is not None:
-                self._chk(lib.lbm_flag_post(stream, self._flag(src, i, 1), before), "lbm_flag_post")
-        for i, (dst, _) in enumerate(self.links):
-            if dst is not None:
-                self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 1), before, self.timeout_ms, self._timed_out), "lbm_flag_await")
-                self._chk(lib.lbm_ipc_copy(stream, self.remote[i], items[i][0].data_ptr(), self.nbytes), "lbm_ipc_copy")
-                self._chk(lib.lbm_flag_post(stream, self._flag(dst, i, 0), q), "lbm_flag_post")
-        for i, (_, src) in enumerate(self.links):
-            if src is not None:
-                self._chk(lib.lbm_flag_await(stream, self._flag(self.rank, i, 0), q, self.timeout_ms, self._timed_out), "lbm_flag_await")
+        # two launches and the copies between them: [post free -> await free] copies [post arrived -> await arrived]
+        srcs = [i for i, (_, src) in enumerate(self.links) if src is not None]
+        dsts = [i for i, (dst, _) in enumerate(self.links) if dst is not None]
+        self._sync(stream, [(self._flag(self.links[i][1], i, 1), before) for i in srcs],
+                   [(self._flag(self.rank, i, 1), before) for i in dsts])
+        for i in dsts:
+            self._chk(lib.lbm_ipc_copy(stream, self.remote[i], items[i][0].data_ptr(), self.nbytes), "lbm_ipc_copy")
+        self._sync(stream, [(self._flag(self.links[i][0], i, 0), q) for i in dsts],
+                   [(self._flag(self.rank, i, 0), q) for i in srcs])
         return ("ipc", None)
+
+    def _sync(self, stream, posts, waits):
+        import ctypes as C
+        pf = (C.c_void_p * max(1, len(posts)))(*[p for p, _ in posts])
+        pv = (C.c_uint32 * max(1, len(posts)))(*[v for _, v in posts])
+        wf = (C.c_void_p * max(1, len(waits)))(*[p for p, _ in waits])
+        wv = (C.c_uint32 * max(1, len(waits)))(*[v for _, v in waits])
+        self._chk(self._lib.lbm_flag_sync(stream, pf, pv, len(posts), wf, wv, len(waits), self.timeout_ms, self._timed_out), "lbm_flag_sync")
 
     def wait(self, handle):
         kind, h = handle

@@ -355,6 +355,11 @@ int lbm_ipc_close(void* d_ptr);
 int lbm_ipc_copy(void* stream, void* d_dst, const void* d_src, size_t bytes);
 int lbm_flag_post(void* stream, uint32_t* d_flag, uint32_t value);
 int lbm_flag_await(void* stream, const uint32_t* d_flag, uint32_t value, uint32_t timeout_ms, uint32_t* d_timed_out);
+/* up to LBM_FLAG_OPS_MAX posts, then up to LBM_FLAG_OPS_MAX waits (one time limit for all of them), in ONE launch: the
+ * posts and waits of an exchange as IpcCopyP2P orders them (the host arrays are read before the call returns) */
+#define LBM_FLAG_OPS_MAX 4
+int lbm_flag_sync(void* stream, uint32_t* const* d_post, const uint32_t* post_values, int nposts,
+                  const uint32_t* const* d_wait, const uint32_t* wait_values, int nwaits, uint32_t timeout_ms, uint32_t* d_timed_out);
 int lbm_flag_peek(const uint32_t* d_flag, uint32_t* value);
 
 #ifdef __cplusplus
