@@ -18,8 +18,12 @@ is parity-checked against the reference's arithmetic is the one that is timed (S
 lid-driven cavity configs[1] names is not a reference boundary set (our own preset); it runs in the `configs` array
 (and as the headline with `--preset cavity`).  Populations resident in HBM.
 N > 1: weak scaling -- every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) tunnel and exchanges the five
-face-crossing populations per face per step with its neighbours by RCCL send/recv (torch.distributed backend
-"nccl"), overlapped with the interior update.
+face-crossing populations per face per step with its neighbours, overlapped with the interior update.  The
+transport (BENCH_TRANSPORT / --transport): "ipc" (default) = peer copies into the neighbours' IPC-mapped receive
+buffers, ordered by flags in fine-grained device memory (cfd_amd/slab.py IpcCopyP2P: no kernel of RCCL's competing
+with the update for CUs), taken only if every rank could map its neighbours' memory and test patterns came through
+every link; otherwise, or with "rccl", RCCL send/recv (torch.distributed backend "nccl").  torch.distributed over RCCL
+carries the rendezvous, the collectives around the timed region and the mask exchange either way.
 --config 2: configs[2], 512x256x256 wind tunnel (reference boundary chain) around the voxelised car stand-in
 (tests/golden/car_like.obj; the reference's mcl35m_2.obj is not in its repository).
 --config 3: configs[3], 1024x512x512 wind tunnel + car, STRONG scaling over z-slabs (512/N layers).
@@ -34,10 +38,10 @@ Beside the headline the one JSON line carries
                     [3], [4] (AA as named and the sliding scheme), the 256^3 wind tunnel with the reference's
                     boundary chain, and the reference-equivalent output modes (rho/u written every step: 172 B per
                     cell; + curl every step: 192 B per cell; lbm_solver.cu:336-337,488);
-  * `strong_scaling` configs[3] split over the N ranks through the z-slab code path (at N = 1: one slab, RCCL
-                    ring to itself): MLUPS, ms per step, halo bytes per step, exposed communication time; at N = 1
+  * `strong_scaling` configs[3] split over the N ranks through the z-slab code path (at N = 1: one slab, its
+                    ring closed on itself): MLUPS, ms per step, halo bytes per step, exposed communication time; at N = 1
                     also `rehearsal_8`: each of the eight 64-layer slabs an 8-GPU run would hold, stepped on this
-                    one GPU (RCCL ring to itself), and `projected_efficiency_8` = T1 / (8 x the slowest slab).
+                    one GPU (ring to itself, same transport), and `projected_efficiency_8` = T1 / (8 x the slowest slab).
 Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 import argparse
@@ -439,7 +443,7 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
     """This rank's z-slab of the domain through the split step + RCCL halo exchange (cfd_amd/slab.py).  `dist` is an
     initialised torch.distributed (world 1: a ring to itself).
     rehearse = (r, P) at world 1: slab r of the P an P-GPU run would hold (layers [r D/P, (r+1) D/P) of the global
-    domain, its share of the obstacle), with its RCCL ring closed on itself: the launches, message sizes and the
+    domain, its share of the obstacle), with its ring closed on itself: the launches, message sizes and the
     two-stream schedule of rank r of P, on one GPU.
     ranges = [(z0, layers)] per part (default: an even split).  params: set_params(**params) instead of the preset's
     defaults (tools/rehearsal_state_probe.py)."""
@@ -640,7 +644,7 @@ def main():
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the `strong_scaling` record (configs[3] over the N ranks)")
     ap.add_argument("--one-step", action="store_true", help="turn the two-steps-per-pass path off (lbm_opts.two_step)")
     ap.add_argument("--rehearse-slab", action="store_true",
-                    help="N = 1 only: run the headline through the z-slab code path of N > 1 (split step, RCCL ring to itself)")
+                    help="N = 1 only: run the headline through the z-slab code path of N > 1 (split step, ring to itself)")
     ap.add_argument("--slab-index", type=int, default=None,
                     help="with --rehearse-slab: rehearse slab R of --slabs (default 8) of the configuration's global domain")
     ap.add_argument("--slabs", type=int, default=8)
@@ -751,7 +755,7 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{preset_name} {W}x{H}x{Dg} D3Q19 fp32, {SCHEME_TEXT[scheme_name]}, "
                                    f"{'voxelised car stand-in, ' if obstacle else ''}"
-                                   f"{('slab ' + str(rehearse[0]) + ' of ' + str(rehearse[1]) + ' rehearsed on one GPU, ' + str(D) + ' layers, RCCL ring to itself') if rehearse else ('z-slabs ' + str(world) + 'x' + str(D) + ' layers, RCCL halo') if slab_path else 'one GPU'}"
+                                   f"{('slab ' + str(rehearse[0]) + ' of ' + str(rehearse[1]) + ' rehearsed on one GPU, ' + str(D) + ' layers, ring to itself: ' + head['transport']) if rehearse else ('z-slabs ' + str(world) + 'x' + str(D) + ' layers, halo exchange: ' + head['transport']) if slab_path else 'one GPU'}"
                                    f" (BASELINE.json configs[{args.config}]"
                                    f"{': its size on the reference boundary chain and defaults; the cavity as named is in `configs`' if args.config == 1 and preset_name == 'wind_tunnel' else ''})",
                        "per_gpu_cells": cells, "per_gpu_fluid_cells": fluid, "bytes_per_cell": BYTES_PER_CELL,
@@ -763,9 +767,9 @@ def main():
             "roofline": head["roofline"],
         }
         if backend == "gloo":
-            out["rehearsal"] = "BENCH_BACKEND=gloo: ranks may share GPUs, messages staged through the host; not a measurement"
+            out["rehearsal"] = "BENCH_BACKEND=gloo: ranks may share GPUs (RCCL's part staged through the host); not a measurement"
         if slab_path:
-            out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "slab_layers", "slab_z0", "slab_ranges", "even_split", "per_rank_ms_no_exchange", "halo_bytes_per_step_per_gpu",
+            out["slab_step"] = {k: head[k] for k in ("rccl_ranks", "transport", "slab_layers", "slab_z0", "slab_ranges", "even_split", "per_rank_ms_no_exchange", "halo_bytes_per_step_per_gpu",
                                                      "ms_per_step_no_exchange", "exposed_comm_ms_per_step") if k in head}
 
     # configs[3] over the N ranks (strong scaling), through the same slab path at every N.  The tunnel around the car
@@ -833,7 +837,7 @@ def main():
                         ss["projected_ms_per_step_8"] = t8
                         ss["projected_efficiency_8"] = round(ss["ms_per_step"] / (8 * t8), 4)
                         ss["projection_note"] = ("T1 / (8 x the slowest of the eight slabs an 8-GPU run would hold), each stepped on this one "
-                                                 "GPU with its RCCL ring closed on itself, slabs cut for equal measured cost as the N > 1 "
+                                                 "GPU with its ring closed on itself (the `transport` of the record), slabs cut for equal measured cost as the N > 1 "
                                                  "run cuts them; no xGMI transfer is in it.  `state_finite` false on a slab: its ring "
                                                  "closes on itself, so where the car's cross-section differs between its two faces "
                                                  "the flow blows up at omega_shear 1.98; the launches and their time do not depend "
