@@ -568,13 +568,16 @@ def run_slabs(lbm, size_global, preset_name, scheme_name, obstacle, steps, warmu
             res["per_rank_ms_no_exchange"] = [round(float(x), 5) for x in own]
             res["ms_per_step_no_exchange"] = round(float(own.max()), 5)
             res["exposed_comm_ms_per_step"] = round(max(0.0, dt / n * 1e3 - float(own.max())), 5)
-        if ipc is not None and any_rank_timed_out():
-            raise RuntimeError("a wait for a neighbour's flag ran into its time limit during the timed region (BENCH_TRANSPORT=rccl avoids the peer copies)")
+        if ipc is not None:
+            if any_rank_timed_out():               # (every rank raises: the flag is max-reduced)
+                raise RuntimeError("a wait for a neighbour's flag ran into its time limit during the timed region (BENCH_TRANSPORT=rccl avoids the peer copies)")
+            ipc.close()                            # collective: every rank is here
+            ipc = None
         return res
     finally:
-        if ipc is not None:
+        if ipc is not None:                        # an error path: the other ranks may never get here, so no barrier
             try:
-                ipc.close()
+                ipc.close(collective=False)
             except Exception as e:                  # noqa: BLE001
                 log("[bench] closing the peer-copy transport:", e)
         solver.close()

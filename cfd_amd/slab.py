@@ -476,16 +476,17 @@ class IpcCopyP2P:
         self._chk(self._lib.lbm_flag_peek(self._timed_out, C.byref(v)), "lbm_flag_peek")
         return v.value != 0
 
-    def _release(self):
-        """collective when world > 1: nobody unmaps or frees memory a neighbour may still write into"""
+    def _release(self, collective=True):
+        """collective when world > 1: nobody unmaps or frees memory a neighbour may still write into
+        (collective=False: an error path, where the other ranks may never get here)"""
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.world > 1 and collective:
             self.dist.barrier()
         self.links, self.recv, self.remote = None, [], []
         for p in self._opened:
             self._lib.lbm_ipc_close(p)
         self._opened, self.peer_block = [], {}
-        if self.world > 1:
+        if self.world > 1 and collective:
             self.dist.barrier()
         for p in self._recv_ptr:
             if p is not None:
@@ -495,10 +496,10 @@ class IpcCopyP2P:
             self._lib.lbm_ipc_free(self.block)
         self.block = None
 
-    def close(self):
-        """collective; the tensors bind() returned are gone afterwards"""
+    def close(self, collective=True):
+        """collective unless told otherwise; the tensors bind() returned are gone afterwards"""
         if self.block is not None or self._opened or self._recv_ptr:
-            self._release()
+            self._release(collective)
 
 
 class SlabSolver:
