@@ -283,7 +283,11 @@ struct GatherAll<PRESET, -1> {
 // re-read so that each XCD gets whole rows: of every 8 consecutive rows of workgroups, row j goes to XCD j.
 // ZORDER_PRIO: the launch runs beside k_fused2 (the boundary layers and the rim of a pair of steps) and something waits
 // for it: its waves raise their issue priority over the long kernel's (s_setprio)
-constexpr int ZORDER_REVERSE = 1, ZORDER_XCD = 2, ZORDER_PRIO = 4;
+// ZORDER_WAVE: workgroups of ONE wave (launched with 64 threads, grid = segments x rows x layers).  For the boundary
+// layers' second step of a pair, which runs beside k_fused2: that kernel's 15 waves per CU leave the registers of three
+// more waves of this one on a CU (118 of 512 per SIMD lane times 4 + 4 + 4 + 3 waves), but not of a workgroup of four,
+// which therefore waited until the fused launch was over (profiles/r03_tuning.md section 12).
+constexpr int ZORDER_REVERSE = 1, ZORDER_XCD = 2, ZORDER_PRIO = 4, ZORDER_WAVE = 8;
 struct TileId {
     int xs, y, lane, bz;
 };
@@ -293,6 +297,10 @@ __device__ __forceinline__ TileId tile_of_wave(int segsx_log2, int zorder) {
     t.lane = threadIdx.x & 63;
     const int segsx = 1 << segsx_log2;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (zorder & ZORDER_WAVE) {
+        t.xs = bx; t.y = by; t.bz = bz;
+        return t;
+    }
     if ((zorder & ZORDER_XCD) && gridDim.x > 1) {
         const unsigned gx = gridDim.x, gy = gridDim.y;
         const unsigned rows = gy * gridDim.z;                     // rows of workgroups in this launch

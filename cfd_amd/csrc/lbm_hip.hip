@@ -112,6 +112,8 @@ struct lbm_ctx {
     long long guard_floats = 0;  // AA: floats allocated in front of f[0]
     int layout = LBM_LAYOUT_ROWS;
     unsigned lds_pad = 0;      // dynamic LDS bytes per block of the step kernel: caps the blocks per CU (occupancy throttle)
+    bool pair_wave_blocks = true;  // the boundary layers' second step of a pair in one-wave workgroups (ZORDER_WAVE; LBM_PAIR_WAVE_BLOCKS=0: off)
+    bool wave_blocks_now = false;  // ... for the launch being issued
     // ---- two steps per pass (k_fused2.h; A/B, undecomposed, row-interleaved layout) ----
     bool fused_on = false;         // lbm_opts.two_step / LBM_FUSED
     bool fused_ready = false;      // eligibility map and rim lists match the current mask
@@ -294,10 +296,12 @@ static int launch_stream_collide(lbm_ctx* c, const float* fin, float* fout, cons
         grid = dim3((unsigned)(ntiles / 4));
     }
     if (c->probe) { const char* t = getenv("LBM_XCD_ROWS"); c->xcd_rows = t ? atoi(t) != 0 : false; }
-    const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | (c->xcd_rows ? ZORDER_XCD : 0) |
-                     (((MODE == 2 || MODE == 4) && c->side_prio && c->fused_usable) ? ZORDER_PRIO : 0);
+    const bool wave_blocks = MODE == 2 && c->wave_blocks_now;
+    if (wave_blocks) grid = dim3(c->g.Wt, c->g.H, nlayers);
+    const int zrev = ((MODE == 0 && (c->tune & 4)) ? c->zrev : 0) | ((c->xcd_rows && !wave_blocks) ? ZORDER_XCD : 0) |
+                     (((MODE == 2 || MODE == 4) && c->side_prio && c->fused_usable) ? ZORDER_PRIO : 0) | (wave_blocks ? ZORDER_WAVE : 0);
 #define LBM_LAUNCH(PRESET, TUNE)                                                                              \
-    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(256), c->lds_pad, stream, fin, fout, c->mask, \
+    hipLaunchKernelGGL((k_stream_collide<PRESET, MODE, TUNE>), grid, dim3(wave_blocks ? 64 : 256), c->lds_pad, stream, fin, fout, c->mask, \
                        c->flags, c->rho, c->u, c->g, p, zl_begin, c->segsx_log2, zrev, zl_second, msg_bottom, msg_top,     \
                        c->ob[c->ob_cur], c->ob[1 - c->ob_cur], want_moments, tile_list)
 #define LBM_LAUNCH_T(PRESET)                          \
@@ -1282,6 +1286,7 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     c->ab_chunk = c->aa_chunk = auto_chunk(g, c->segsx_log2);
     if (const char* t = getenv("LBM_AB_CHUNK")) c->ab_chunk = c->aa_chunk = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_LDS_PAD")) c->lds_pad = (unsigned)atoi(t);
+    if (const char* t = getenv("LBM_PAIR_WAVE_BLOCKS")) c->pair_wave_blocks = atoi(t) != 0;
     c->fused_on = o.two_step != LBM_TWO_STEP_OFF;
     if (const char* t = getenv("LBM_FUSED")) c->fused_on = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_ZSPLIT")) c->f2_zsplit = std::max(0, atoi(t));
@@ -2395,7 +2400,10 @@ int lbm_pair_boundary_second(lbm_ctx* c, float* d_msg_bottom, float* d_msg_top) 
     hipStream_t bs = c->stream_b ? c->stream_b : c->stream;
     if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(bs, c->ev_pair_r1, 0));
     // second step of the two boundary layers: t+1 -> t+2, from the intermediate buffer (ghost layers just unpacked)
+    // (beside the fused kernel: in workgroups of one wave, which find room on the CUs that kernel fills)
+    c->wave_blocks_now = c->pair_wave_blocks;
     int rc = launch_stream_collide<2>(c, c->ft, c->f[1 - c->cur], c->p, 1, 2, c->g.D, d_msg_bottom, d_msg_top, 0, bs);
+    c->wave_blocks_now = false;
     if (rc) return rc;
     c->pair_phase = 3;
     return LBM_OK;
