@@ -1,5 +1,6 @@
 #!/bin/bash
 # the rim of the undecomposed path beside the fused kernel, in workgroups of four waves and of one
+# (LBM_RIM_WAVE_BLOCKS existed in a probe build only, profiles/r03_tuning.md section 12: without it the "wave" lines repeat the others)
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
