@@ -44,6 +44,46 @@ struct FusedGrid {
     int wide;               // plain blocks take the wide form of the first-step loads (LBM_FUSED_WIDE=0 turns it off)
 };
 
+// The rim's FIRST step (the rim tiles and the tiles next to them, t -> t+1 into the intermediate buffer) reads the buffer
+// the blocks read and writes one they do not touch, so it needs no launch of its own: the workgroups BEHIND the last block
+// of the list take its tile list, one entry per wave (k_stream_collide's MODE 4 entries: xs | y << 16 | zl << 40, ~0 pads).
+// They are dispatched when the blocks have all started, i.e. onto the CUs that hold no block and onto those whose block
+// has ended -- the tail of the launch, where the tile columns at the x ends of the domain leave their CUs idle for the
+// last tenth of it -- and one kernel boundary of a pair of steps goes away (profiles/r03_tuning.md section 13).
+struct F2Rim {
+    const unsigned long long* list;   // nullptr / n = 0: the rim's first step has a launch of its own
+    const unsigned long long* mask;
+    const unsigned char* flags;
+    float* ft;
+    unsigned n;
+};
+template <int PRESET>
+__device__ __forceinline__ void f2_rim_tile(const float* __restrict__ fin, const F2Rim& rim, const Geo& g, const Params& p,
+                                            unsigned long long e, int lane) {
+    if (e == ~0ull) return;
+    const int xs = (int)(e & 0xffffu), y = (int)((e >> 16) & 0xffffffu), zl = (int)(e >> 40);
+    if (xs >= g.Wt || y >= g.H) return;
+    const int x = xs * 64 + lane;
+    const unsigned char flag = rim.flags[((long long)(zl - 1) * g.H + y) * g.Wt + xs];
+    if (x >= g.W || flag == 2) return;
+    const long long own = cell_off(g, x, y, zl);
+    const float inlet_e = inlet_bracket(p.U);
+    float f[Q];
+    if (flag == 0) {
+        GatherAll<PRESET, Q - 1>::template fast<1>(g, fin, x, y, zl, own, inlet_e, f);
+    } else {
+        const TileMask tm = load_tile_mask(g, rim.mask, xs, y, zl);
+        if ((tm.w[1][1] >> lane) & 1ull) return;      // a solid cell: frozen in every buffer (k_sync_solid)
+        GatherAll<PRESET, Q - 1>::template general<false>(g, fin, tm, lane, x, y, zl, own, inlet_e, p.U, nullptr, f);
+    }
+    const Moments m = moments_of(f);
+    float o[Q];
+    collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
+    float* dst = rim.ft + own;
+#pragma unroll
+    for (int k = 0; k < Q; k++) stf<1>(dst + (long long)k * g.plane, o[k]);
+}
+
 // populations whose first-step loads carry the non-temporal hint (bit k), as LBM_NT_SET for the one-step kernel
 #ifndef F2_NT_SET
 #define F2_NT_SET 0u
@@ -478,7 +518,12 @@ template <int PRESET, int TY, int STAGE, int NBUF, int OBST, int WALL>
 __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restrict__ fin, float* __restrict__ fout,
                                                           const unsigned long long* __restrict__ blocks,
                                                           const unsigned* __restrict__ nbw, Geo g, Params p,
-                                                          FusedGrid fg, unsigned long long* __restrict__ stamps) {
+                                                          FusedGrid fg, unsigned long long* __restrict__ stamps, F2Rim rim) {
+    if (blockIdx.x >= (unsigned)fg.nblocks) {   // behind the block list: the rim's first step, one tile per wave
+        const unsigned idx = (blockIdx.x - (unsigned)fg.nblocks) * (unsigned)(TY + 3) + (threadIdx.x >> 6);
+        if (idx < rim.n) f2_rim_tile<PRESET>(fin, rim, g, p, rim.list[idx], threadIdx.x & 63);
+        return;
+    }
     // One workgroup per block of the host's list (fused_prepare() in lbm_hip.hip: a 64 x TY tile and a run of
     // layers whose haloed neighbourhood is plain fluid, ordered layer range / y tile / x tile; the rim path owns
     // every other cell).  The hardware deals workgroups to the 8 XCDs round-robin in launch

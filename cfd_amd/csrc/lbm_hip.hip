@@ -142,6 +142,9 @@ struct lbm_ctx {
     long long rim_cells = 0;       // cells of the rim tiles (second list)
     hipStream_t stream_rim = nullptr;   // library-owned side stream: the rim's two small launches run beside k_fused2
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
+    bool f2_tail_rim = true;       // the rim's first step behind the block list of the fused launch (k_fused2.h F2Rim; LBM_FUSED_TAIL_RIM=0: a launch of its own)
+    int f2_tail_pct = 4;           // ... when the rim is more than this share of the cells (LBM_FUSED_TAIL_PCT)
+    bool f2_tail_now = false;      // ... for the launch being issued
     bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
     int f2_overlap_pct = 15;       // LBM_FUSED_OVERLAP_PCT: side stream when the rim is more than this share of the cells
     bool f2_rim_pending = false;   // the side stream holds rim launches the context's stream has not waited for yet
@@ -488,8 +491,15 @@ static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout)
         if (e != hipSuccess) return e;
         attr_set[c->device] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(c->fg.nblocks), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
-                       c->f2_nbw, c->g, c->p, c->fg, c->f2_stamps);
+    // the rim's first step rides behind the block list (F2Rim) when the caller asked for it
+    F2Rim rim{nullptr, nullptr, nullptr, nullptr, 0u};
+    unsigned rim_wgs = 0;
+    if (c->f2_tail_now && c->rim_n[0] > 0) {
+        rim = F2Rim{c->rim_list[0], c->mask, c->flags, c->ft, (unsigned)c->rim_n[0]};
+        rim_wgs = (unsigned)((c->rim_n[0] + (TY + 3) - 1) / (TY + 3));
+    }
+    hipLaunchKernelGGL(kern, dim3(c->fg.nblocks + rim_wgs), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
+                       c->f2_nbw, c->g, c->p, c->fg, c->f2_stamps, rim);
     return hipGetLastError();
 }
 template <int PRESET, int TY, int STAGE, int NBUF>
@@ -1057,15 +1067,21 @@ static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
 }
 
 // two time steps: t (f[cur]) -> t+2 (f[1-cur]).  `first`: the first pair of a batch.
-// The rim's two launches touch no cell the fused kernel touches, so they run on a side stream beside it; both
-// streams meet again before the next pair (which reads everything this one wrote) and after the last one.
+// The rim's two launches touch no cell the fused kernel touches; where they run depends on how big the rim is (below).
+// In the side-stream mode both streams meet again before the next pair (which reads everything this one wrote) and
+// after the last one.
 static int fused_pair(lbm_ctx* c, bool first) {
     const float* in = c->f[c->cur];
     float* out = c->f[1 - c->cur];
     hipStream_t rim_stream = c->stream;
-    // worth it when the rim is a good part of the domain (obstacles: +3 % at 512x256x256 + car); around an empty
-    // box the two small launches cost the same beside the fused kernel as behind it
-    const bool overlap = c->f2_overlap && c->rim_cells * 100 > cells(c) * c->f2_overlap_pct;
+    // A rim that is more than a few per cent of the domain (obstacles, small domains) should not wait behind the fused
+    // kernel with three kernel boundaries per pair: its first step rides in the tail of the fused launch (k_fused2.h
+    // F2Rim; 512x256x256 + car, rim 6 %: 52 480 -> 53 440 MLUPS; 400x100x100: 43 640 -> 45 120).  Around a large empty box
+    // (rim 3 %) the small launches cost the same or less behind the fused kernel (256^3: 0.2993 ms per step against 0.3012
+    // with the tail, 0.3165 with both on a side stream).  LBM_FUSED_TAIL_RIM=0: the earlier rule -- both rim launches on
+    // a side stream beside the fused kernel when the rim is more than 15 %.
+    const bool tail = c->f2_tail_rim && c->rim_cells * 100 > cells(c) * c->f2_tail_pct;
+    const bool overlap = c->f2_overlap && !tail && c->rim_cells * 100 > cells(c) * c->f2_overlap_pct;
     if (overlap) {
         if (!c->stream_rim) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
@@ -1077,9 +1093,11 @@ static int fused_pair(lbm_ctx* c, bool first) {
         HIPCHK(c, hipEventRecord(c->ev_f2_main, c->stream));                       // ... and its fused launch, and all before
         HIPCHK(c, hipStreamWaitEvent(rim_stream, c->ev_f2_main, 0));
     }
+    c->f2_tail_now = tail;
     int rc = launch_fused_timed(c, in, out);
+    c->f2_tail_now = false;
     if (rc) return rc;
-    rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[0], c->rim_n[0]);
+    if (!tail) rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[0], c->rim_n[0]);
     if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[1], c->rim_n[1]);
     if (rc) return rc;
     if (overlap) HIPCHK(c, hipEventRecord(c->ev_f2_rim, rim_stream));
@@ -1297,6 +1315,8 @@ int lbm_create(lbm_ctx** out, int width, int height, int depth, const lbm_opts* 
     if (const char* t = getenv("LBM_PAIR_RIM_STREAM")) c->pair_rim_stream = atoi(t) != 0;
     if (const char* t = getenv("LBM_SIDE_PRIO")) c->side_prio = atoi(t) != 0;
     if (const char* t = getenv("LBM_FUSED_OVERLAP")) c->f2_overlap = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_TAIL_RIM")) c->f2_tail_rim = atoi(t) != 0;
+    if (const char* t = getenv("LBM_FUSED_TAIL_PCT")) c->f2_tail_pct = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_OVERLAP_PCT")) c->f2_overlap_pct = std::max(0, atoi(t));
     if (const char* t = getenv("LBM_FUSED_VARIANT")) {
         int ty = 0, st = 0, nb = 0;

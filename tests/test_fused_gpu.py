@@ -88,6 +88,29 @@ def test_even_batches_end_on_a_pair(oracle, lbm, preset):
     np.testing.assert_array_equal(g.density(), np.asarray(o.density()).reshape(D, H, W)[3:8].ravel())
 
 
+@pytest.mark.parametrize("preset", [0, 1])
+@pytest.mark.parametrize("where", ["tail", "behind", "side"])
+def test_where_the_rim_runs(oracle, lbm, preset, where, monkeypatch):
+    """the rim's first step in the tail of the fused launch (k_fused2.h F2Rim: the workgroups behind the block list),
+    both rim launches behind the fused kernel, or both on a side stream beside it: the same cells either way"""
+    env = {"tail": {"LBM_FUSED_TAIL_PCT": "0"},
+           "behind": {"LBM_FUSED_TAIL_RIM": "0", "LBM_FUSED_OVERLAP": "0"},
+           "side": {"LBM_FUSED_TAIL_RIM": "0", "LBM_FUSED_OVERLAP_PCT": "0"}}[where]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H, D = 200, 41, 38
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    for s in (o, g):
+        s.init()
+        s.add_solid(60, 0, 10, 22, 15, 12)
+        s.add_solid(W - 2, 20, 5, 2, 6, 9)
+    for n in (7, 4, 12):
+        o.step(n); g.step(n)
+        same(o, g, f"preset {preset}, rim {where}, after {n} steps")
+    fused_in_use(lbm, g)
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("zsplit", [0, 1, 3])
 def test_fused_variants_with_obstacles(oracle, lbm, variant, zsplit, monkeypatch):
