@@ -274,9 +274,11 @@ def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kern
     two_step = bool(fl and fms > 0)
     if two_step:
         launch_ms = fms / fl
-        updates = 2 * stats["fused_cells"]
+        # (+ the rim's first step where it rides in the tail of the same launch: those cells advance by ONE step)
+        tail = stats.get("fused_tail_cells", 0)
+        updates = 2 * stats["fused_cells"] + tail
         name, launches_per_step = "k_fused2", fl / steps
-        algorithmic = stats["fused_cells"] * bytes_per_cell       # one read + one write of every cell of the blocks
+        algorithmic = (stats["fused_cells"] + tail) * bytes_per_cell   # one read + one write of every cell the launch touches
     else:
         launches = max(1, stats["last_timed_launches"])
         launch_ms = dev_ms / launches
@@ -290,6 +292,8 @@ def roofline_of(stats, dev_ms, steps, fluid, bytes_per_cell=BYTES_PER_CELL, kern
            "launch_ms": round(launch_ms, 5), "launches_per_step": round(launches_per_step, 3),
            "algorithmic_bytes_per_launch": round(algorithmic), "cell_updates_per_launch": round(updates),
            "bytes_per_cell_update": bytes_per_cell // 2 if two_step else bytes_per_cell}
+    if two_step and tail:
+        out["tail_cell_updates_per_launch"] = tail      # one step each, 152 B per update; the blocks' cells: two steps, 76 B per update
     # which form of its first-step loads k_fused2 settled on for this plan (timed by the library on the first launch)
     loads = {1: "wide", 0: "narrow"}.get(stats.get("fused_wide_loads", -1)) if two_step else None
     if loads:

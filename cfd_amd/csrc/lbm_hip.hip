@@ -140,6 +140,7 @@ struct lbm_ctx {
     size_t rim_n[2] = {0, 0}, rim_cap[2] = {0, 0};          // entries, padded to a multiple of 4
     long long fused_cells = 0;     // cells one k_fused2 launch updates (twice each)
     long long rim_cells = 0;       // cells of the rim tiles (second list)
+    long long tail_cells = 0;      // cells of the rim's first step (first list: the rim tiles and the tiles next to them)
     hipStream_t stream_rim = nullptr;   // library-owned side stream: the rim's two small launches run beside k_fused2
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
     bool f2_tail_rim = true;       // the rim's first step behind the block list of the fused launch (k_fused2.h F2Rim; LBM_FUSED_TAIL_RIM=0: a launch of its own)
@@ -942,7 +943,7 @@ static int fused_prepare(lbm_ctx* c) {
             for (int xs = 0; xs < g.Wt; xs++)
                 a[tile(xs, y, z)] = b[tile(xs, y, z)] | (z > 0 ? b[tile(xs, y, z - 1)] : 0) | (z + 1 < g.D ? b[tile(xs, y, z + 1)] : 0);
     std::vector<unsigned long long> list[2];
-    long long rim_cells = 0;
+    long long rim_cells = 0, tail_cells = 0;
     for (int z = 0; z < g.D; z++)
         for (int y = 0; y < g.H; y++)
             for (int xs = 0; xs < g.Wt; xs++) {
@@ -950,7 +951,7 @@ static int fused_prepare(lbm_ctx* c) {
                 if (fl[t] == 2) continue;
                 if (g.slab && (z == 0 || z == g.D - 1)) continue;   // a slab's boundary layers: lbm_pair_boundary_*()
                 const unsigned long long e = (unsigned long long)xs | ((unsigned long long)y << 16) | ((unsigned long long)(z + 1) << 40);
-                if (a[t]) list[0].push_back(e);
+                if (a[t]) { list[0].push_back(e); tail_cells += std::min(64, g.W - xs * 64); }
                 if (rim[t]) { list[1].push_back(e); rim_cells += std::min(64, g.W - xs * 64); }
             }
     for (auto& l : list)
@@ -985,6 +986,7 @@ static int fused_prepare(lbm_ctx* c) {
     c->fg = fg;
     c->fused_cells = fused_cells;
     c->rim_cells = rim_cells;
+    c->tail_cells = tail_cells;
     c->fused_usable = true;
     return LBM_OK;
 }
@@ -1066,6 +1068,11 @@ static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
     return LBM_OK;
 }
 
+// the rim's first step inside the fused launch (undecomposed contexts; F2Rim in k_fused2.h)
+static bool fused_tail_rim(const lbm_ctx* c) {
+    return c->f2_tail_rim && !c->g.slab && c->rim_cells * 100 > cells(c) * c->f2_tail_pct;
+}
+
 // two time steps: t (f[cur]) -> t+2 (f[1-cur]).  `first`: the first pair of a batch.
 // The rim's two launches touch no cell the fused kernel touches; where they run depends on how big the rim is (below).
 // In the side-stream mode both streams meet again before the next pair (which reads everything this one wrote) and
@@ -1080,7 +1087,7 @@ static int fused_pair(lbm_ctx* c, bool first) {
     // (rim 3 %) the small launches cost the same or less behind the fused kernel (256^3: 0.2993 ms per step against 0.3012
     // with the tail, 0.3165 with both on a side stream).  LBM_FUSED_TAIL_RIM=0: the earlier rule -- both rim launches on
     // a side stream beside the fused kernel when the rim is more than 15 %.
-    const bool tail = c->f2_tail_rim && c->rim_cells * 100 > cells(c) * c->f2_tail_pct;
+    const bool tail = fused_tail_rim(c);
     const bool overlap = c->f2_overlap && !tail && c->rim_cells * 100 > cells(c) * c->f2_overlap_pct;
     if (overlap) {
         if (!c->stream_rim) {
@@ -2059,6 +2066,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->fused_wide_loads = !c->fused_usable ? -1 : (c->f2_wide_pending ? -1 : c->fg.wide);
     out->fused_tuned_ms[0] = c->f2_wide_ms[0];
     out->fused_tuned_ms[1] = c->f2_wide_ms[1];
+    out->fused_tail_cells = (uint64_t)((c->fused_usable && fused_tail_rim(c)) ? c->tail_cells : 0);
     return LBM_OK;
 }
 

@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("last_timed_steps", C.c_uint64), ("last_timed_launches", C.c_uint64),
                 ("fused_cells", C.c_uint64), ("rim_cells", C.c_uint64),
                 ("last_timed_fused_launches", C.c_uint64), ("last_timed_fused_ms", C.c_double),
-                ("fused_wide_loads", C.c_int32), ("fused_tuned_ms", C.c_float * 2)]
+                ("fused_wide_loads", C.c_int32), ("fused_tuned_ms", C.c_float * 2), ("fused_tail_cells", C.c_uint64)]
 
 
 # every symbol include/lbm_abi.h declares, with its ctypes signature

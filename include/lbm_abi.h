@@ -126,6 +126,9 @@ typedef struct lbm_stats {
      * plan (LBM_FUSED_WIDE unset), neither form wins everywhere */
     int32_t  fused_wide_loads;    /* 1 wide (16-byte loads of whole rows), 0 narrow, -1 not decided yet */
     float    fused_tuned_ms[2];   /* what one launch took when they were timed: narrow, wide (0: never timed) */
+    /* cells that the SAME launch advances by ONE step: the rim's first step, when it rides in the tail of the fused
+     * launch (undecomposed contexts whose rim is more than a few per cent of the cells; 0 otherwise) */
+    uint64_t fused_tail_cells;
 } lbm_stats;
 
 /* lbm_solver::lbm_solver(int,int,int)  -- lbm_solver.cu:404-453.  opts may be NULL. */

@@ -49,11 +49,16 @@ with open(os.path.join(dst, f"{prefix}_{tag}_pmc_traffic.txt"), "w") as f:
     f.write(f"  {vals['FETCH_SIZE'][2][:110]}\n")
     f.write(f"FETCH_SIZE avg {vals['FETCH_SIZE'][0]:.1f} KiB over {vals['FETCH_SIZE'][1]} dispatches -> x1024 x2 (gfx950 half-count) = {fetch_b:.0f} B\n")
     f.write(f"WRITE_SIZE avg {vals['WRITE_SIZE'][0]:.1f} KiB over {vals['WRITE_SIZE'][1]} dispatches -> x1024 = {write_b:.0f} B\n")
-    f.write(f"traffic per launch = {fetch_b + write_b:.0f} B; algorithmic ({b['roofline']['bytes_per_cell_update']} B x {b['roofline']['cell_updates_per_launch']} cell updates) = {alg} B; ratio {(fetch_b + write_b) / alg:.4f}\n")
+    tail = b["roofline"].get("tail_cell_updates_per_launch", 0)   # the rim's first step riding in the fused launch: one update per cell
+    if tail:
+        f.write(f"traffic per launch = {fetch_b + write_b:.0f} B; algorithmic (76 B x {b['roofline']['cell_updates_per_launch'] - tail} updates of the blocks' cells "
+                f"+ 152 B x {tail} updates of the rim's first step in the launch's tail) = {alg} B; ratio {(fetch_b + write_b) / alg:.4f}\n")
+    else:
+        f.write(f"traffic per launch = {fetch_b + write_b:.0f} B; algorithmic ({b['roofline']['bytes_per_cell_update']} B x {b['roofline']['cell_updates_per_launch']} cell updates) = {alg} B; ratio {(fetch_b + write_b) / alg:.4f}\n")
     f.write(f"reads / algorithmic reads = {fetch_b / (alg / 2):.4f}; writes / algorithmic writes = {write_b / (alg / 2):.4f}\n")
     if dominant == "k_fused2":
-        cells = b["roofline"]["cell_updates_per_launch"] / 2
-        f.write(f"per cell of the fused region and launch (two updates): {fetch_b / cells:.1f} B read + {write_b / cells:.1f} B written "
+        cells = (b["roofline"]["cell_updates_per_launch"] - tail) / 2 + tail
+        f.write(f"per cell the launch touches (two updates; one for the cells of a rim tail): {fetch_b / cells:.1f} B read + {write_b / cells:.1f} B written "
                 f"(one read + one write of the 19 populations = 76 + 76 B; the rest of the reads is the tile halo and the two lead-in layers of a z chunk)\n")
     for k, d in sorted(per_kernel.items()):
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
