@@ -309,6 +309,29 @@ def test_fused_equals_single_steps_256(lbm, preset_name, wide, monkeypatch):
     assert np.array_equal(fa, fb)
 
 
+def test_fused_equals_single_steps_car(lbm):
+    """BASELINE.json configs[2] at full size (512 x 256 x 256 wind tunnel + the voxelised car stand-in): 21 + 12 steps fused
+    -- blocks running through the car, the rim's first step in the tail of the fused launch (rim 6 % of the cells), an
+    even call ending on a pair -- against single steps"""
+    import os
+    car = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "car_like.obj")
+    a = lbm.Solver(512, 256, 256, lbm.PRESET_WIND_TUNNEL, two_step=lbm.TWO_STEP_OFF)
+    b = lbm.Solver(512, 256, 256, lbm.PRESET_WIND_TUNNEL)
+    for s in (a, b):
+        s.init()
+        s.load_mesh(car)
+        s.step(21)
+        s.step(12)
+    assert a.stats()["fused_cells"] == 0
+    if fused_in_use(lbm, b):
+        st = b.stats()
+        assert st["fused_cells"] > 512 * 256 * 256 // 2 and st["fused_tail_cells"] > 0, st
+    np.testing.assert_array_equal(a.density(), b.density())
+    np.testing.assert_array_equal(a.velocity(), b.velocity())
+    assert np.array_equal(a.populations(), b.populations())
+    a.close(); b.close()
+
+
 def test_fused_blocks_hold_obstacles(oracle, lbm, monkeypatch):
     """blocks run THROUGH obstacles (the kernel bounces back from solid cells itself, solid cells are never
     stored): a thin plate, a staircase, a box touching the floor, single cells; with LBM_FUSED_OBST=0 the
