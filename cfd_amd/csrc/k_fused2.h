@@ -44,22 +44,25 @@ struct FusedGrid {
     int wide;               // plain blocks take the wide form of the first-step loads (LBM_FUSED_WIDE=0 turns it off)
 };
 
-// The rim's FIRST step (the rim tiles and the tiles next to them, t -> t+1 into the intermediate buffer) reads the buffer
-// the blocks read and writes one they do not touch, so it needs no launch of its own: the workgroups BEHIND the last block
-// of the list take its tile list, one entry per wave (k_stream_collide's MODE 4 entries: xs | y << 16 | zl << 40, ~0 pads).
-// They are dispatched when the blocks have all started, i.e. onto the CUs that hold no block and onto those whose block
-// has ended -- the tail of the launch, where the tile columns at the x ends of the domain leave their CUs idle for the
-// last tenth of it -- and one kernel boundary of a pair of steps goes away (profiles/r03_tuning.md section 13).
+// One of the rim's two steps can ride in the fused launch: it writes cells no block touches, and what it reads is
+// complete before the launch starts.  Undecomposed contexts: the FIRST step (the rim tiles and the tiles next to them,
+// t -> t+1 from the buffer the blocks read into the intermediate one).  z-slabs: the SECOND (t+1 -> t+2 from the
+// intermediate buffer into the blocks' output buffer; the first must end early there, the boundary layers' second step
+// waits for it).  The workgroups BEHIND the last block of the list take that step's tile list, one entry per wave
+// (k_stream_collide's MODE 4 entries: xs | y << 16 | zl << 40, ~0 pads).  They are dispatched when the blocks have all
+// started, i.e. onto the CUs that hold no block and onto those whose block has ended -- the ragged tail of a launch of
+// several rounds -- and one kernel boundary of a pair of steps goes away (profiles/r03_tuning.md section 13).
 struct F2Rim {
-    const unsigned long long* list;   // nullptr / n = 0: the rim's first step has a launch of its own
+    const unsigned long long* list;   // nullptr / n = 0: both steps of the rim have launches of their own
     const unsigned long long* mask;
     const unsigned char* flags;
-    float* ft;
+    const float* src;
+    float* dst;
     unsigned n;
 };
 template <int PRESET>
-__device__ __forceinline__ void f2_rim_tile(const float* __restrict__ fin, const F2Rim& rim, const Geo& g, const Params& p,
-                                            unsigned long long e, int lane) {
+__device__ __forceinline__ void f2_rim_tile(const F2Rim& rim, const Geo& g, const Params& p, unsigned long long e, int lane) {
+    const float* __restrict__ fin = rim.src;
     if (e == ~0ull) return;
     const int xs = (int)(e & 0xffffu), y = (int)((e >> 16) & 0xffffffu), zl = (int)(e >> 40);
     if (xs >= g.Wt || y >= g.H) return;
@@ -79,7 +82,7 @@ __device__ __forceinline__ void f2_rim_tile(const float* __restrict__ fin, const
     const Moments m = moments_of(f);
     float o[Q];
     collide_cell(f, m, p.omega_shear, p.omega_bulk, o);
-    float* dst = rim.ft + own;
+    float* dst = rim.dst + own;
 #pragma unroll
     for (int k = 0; k < Q; k++) stf<1>(dst + (long long)k * g.plane, o[k]);
 }
@@ -519,9 +522,9 @@ __global__ __launch_bounds__((TY + 3) * 64) void k_fused2(const float* __restric
                                                           const unsigned long long* __restrict__ blocks,
                                                           const unsigned* __restrict__ nbw, Geo g, Params p,
                                                           FusedGrid fg, unsigned long long* __restrict__ stamps, F2Rim rim) {
-    if (blockIdx.x >= (unsigned)fg.nblocks) {   // behind the block list: the rim's first step, one tile per wave
+    if (blockIdx.x >= (unsigned)fg.nblocks) {   // behind the block list: a step of the rim, one tile per wave
         const unsigned idx = (blockIdx.x - (unsigned)fg.nblocks) * (unsigned)(TY + 3) + (threadIdx.x >> 6);
-        if (idx < rim.n) f2_rim_tile<PRESET>(fin, rim, g, p, rim.list[idx], threadIdx.x & 63);
+        if (idx < rim.n) f2_rim_tile<PRESET>(rim, g, p, rim.list[idx], threadIdx.x & 63);
         return;
     }
     // One workgroup per block of the host's list (fused_prepare() in lbm_hip.hip: a 64 x TY tile and a run of

@@ -145,7 +145,8 @@ struct lbm_ctx {
     hipEvent_t ev_f2_main = nullptr, ev_f2_rim = nullptr;
     bool f2_tail_rim = true;       // the rim's first step behind the block list of the fused launch (k_fused2.h F2Rim; LBM_FUSED_TAIL_RIM=0: a launch of its own)
     int f2_tail_pct = 4;           // ... when the rim is more than this share of the cells (LBM_FUSED_TAIL_PCT)
-    bool f2_tail_now = false;      // ... for the launch being issued
+    int f2_rounds = 1;             // rounds of blocks a fused launch runs in (blocks / CUs, rounded up)
+    int f2_tail_now = 0;           // ... for the launch being issued: 1 the rim's first step, 2 its second (slabs)
     bool f2_overlap = true;        // LBM_FUSED_OVERLAP=0: everything on the context's stream
     int f2_overlap_pct = 15;       // LBM_FUSED_OVERLAP_PCT: side stream when the rim is more than this share of the cells
     bool f2_rim_pending = false;   // the side stream holds rim launches the context's stream has not waited for yet
@@ -492,12 +493,14 @@ static hipError_t launch_fused_kernel(lbm_ctx* c, const float* fin, float* fout)
         if (e != hipSuccess) return e;
         attr_set[c->device] = true;
     }
-    // the rim's first step rides behind the block list (F2Rim) when the caller asked for it
-    F2Rim rim{nullptr, nullptr, nullptr, nullptr, 0u};
+    // a step of the rim rides behind the block list (F2Rim) when the caller asked for it: 1 = its first step (fin -> ft,
+    // undecomposed contexts), 2 = its second (ft -> fout, z-slabs)
+    F2Rim rim{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     unsigned rim_wgs = 0;
-    if (c->f2_tail_now && c->rim_n[0] > 0) {
-        rim = F2Rim{c->rim_list[0], c->mask, c->flags, c->ft, (unsigned)c->rim_n[0]};
-        rim_wgs = (unsigned)((c->rim_n[0] + (TY + 3) - 1) / (TY + 3));
+    const int which = c->f2_tail_now - 1;
+    if (which >= 0 && c->rim_n[which] > 0) {
+        rim = F2Rim{c->rim_list[which], c->mask, c->flags, which == 0 ? fin : c->ft, which == 0 ? c->ft : fout, (unsigned)c->rim_n[which]};
+        rim_wgs = (unsigned)((c->rim_n[which] + (TY + 3) - 1) / (TY + 3));
     }
     hipLaunchKernelGGL(kern, dim3(c->fg.nblocks + rim_wgs), dim3((TY + 3) * 64), lds, c->stream, fin, fout, c->f2_blocks,
                        c->f2_nbw, c->g, c->p, c->fg, c->f2_stamps, rim);
@@ -910,6 +913,7 @@ static int fused_prepare(lbm_ctx* c) {
             longest = std::max(longest, best.range[xcd + 1] - best.range[xcd]);
         }
         fg.nblocks = (int)(8 * longest);
+        c->f2_rounds = (fg.nblocks + ncu - 1) / ncu;
     }
     if (const char* dbg = getenv("LBM_FUSED_DEBUG"))
         if (dbg[0] == '4')   // the block list in launch order (tools/chain_spread.py --blocks joins it with the stamps)
@@ -1069,9 +1073,18 @@ static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
 }
 
 // the rim's first step inside the fused launch (undecomposed contexts; F2Rim in k_fused2.h)
-static bool fused_tail_rim(const lbm_ctx* c) {
-    return c->f2_tail_rim && !c->g.slab && c->rim_cells * 100 > cells(c) * c->f2_tail_pct;
+// Pays where the launch has a ragged tail -- several rounds of blocks with the narrow first-step loads (obstacles, thin
+// slabs) -- or the rim is more than a few per cent of the cells.  With the wide loads every block issues the same requests
+// and all end within a microsecond of each other, in one round or in eight: such a launch only gets longer by the rim's
+// step (256^3 -0.6 %, 512^3 -0.9 %; profiles/r03_tuning.md section 13).  Not while the library is still timing the two
+// forms of the loads against each other: both are timed without it.
+static bool fused_tail_pays(const lbm_ctx* c) {
+    if (!c->f2_tail_rim || c->f2_wide_pending) return false;
+    return (c->f2_rounds > 1 && !c->fg.wide) || c->rim_cells * 100 > cells(c) * c->f2_tail_pct;
 }
+static bool fused_tail_rim(const lbm_ctx* c) { return !c->g.slab && fused_tail_pays(c); }
+// ... on a z-slab: the rim's SECOND step (lbm_pair_interior)
+static bool fused_tail_rim_slab(const lbm_ctx* c) { return c->g.slab && !c->pair_rim_stream && fused_tail_pays(c); }
 
 // two time steps: t (f[cur]) -> t+2 (f[1-cur]).  `first`: the first pair of a batch.
 // The rim's two launches touch no cell the fused kernel touches; where they run depends on how big the rim is (below).
@@ -1100,9 +1113,9 @@ static int fused_pair(lbm_ctx* c, bool first) {
         HIPCHK(c, hipEventRecord(c->ev_f2_main, c->stream));                       // ... and its fused launch, and all before
         HIPCHK(c, hipStreamWaitEvent(rim_stream, c->ev_f2_main, 0));
     }
-    c->f2_tail_now = tail;
+    c->f2_tail_now = tail ? 1 : 0;
     int rc = launch_fused_timed(c, in, out);
-    c->f2_tail_now = false;
+    c->f2_tail_now = 0;
     if (rc) return rc;
     if (!tail) rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[0], c->rim_n[0]);
     if (!rc) rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rim_stream, c->rim_list[1], c->rim_n[1]);
@@ -2066,7 +2079,7 @@ int lbm_get_stats(lbm_ctx* c, lbm_stats* out) {
     out->fused_wide_loads = !c->fused_usable ? -1 : (c->f2_wide_pending ? -1 : c->fg.wide);
     out->fused_tuned_ms[0] = c->f2_wide_ms[0];
     out->fused_tuned_ms[1] = c->f2_wide_ms[1];
-    out->fused_tail_cells = (uint64_t)((c->fused_usable && fused_tail_rim(c)) ? c->tail_cells : 0);
+    out->fused_tail_cells = (uint64_t)(!c->fused_usable ? 0 : fused_tail_rim(c) ? c->tail_cells : fused_tail_rim_slab(c) ? c->rim_cells : 0);
     return LBM_OK;
 }
 
@@ -2408,12 +2421,20 @@ int lbm_pair_interior(lbm_ctx* c) {
     int rc = launch_stream_collide<4>(c, in, c->ft, c->p, 0, 1, 0, nullptr, nullptr, 0, rs, c->rim_list[0], c->rim_n[0]);
     if (rc) return rc;
     if (bs != c->stream) HIPCHK(c, hipEventRecord(c->ev_pair_r1, rs));
+    // the rim's second step pulls from the boundary layers' first step.  With a rim of more than a few per cent it rides
+    // in the tail of the fused launch (F2Rim), which then has to start behind that step of the boundary layers -- a short
+    // kernel that runs beside the rim's first step
+    const bool tail = fused_tail_rim_slab(c);
+    if (tail && bs != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pair_b1, 0));
+    c->f2_tail_now = tail ? 2 : 0;
     rc = launch_fused_timed(c, in, out);
+    c->f2_tail_now = 0;
     if (rc) return rc;
-    // the rim's second step pulls from the boundary layers' first step
-    if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(rs, c->ev_pair_b1, 0));
-    rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rs, c->rim_list[1], c->rim_n[1]);
-    if (rc) return rc;
+    if (!tail) {
+        if (bs != c->stream) HIPCHK(c, hipStreamWaitEvent(rs, c->ev_pair_b1, 0));
+        rc = launch_stream_collide<4>(c, c->ft, out, c->p, 0, 1, 0, nullptr, nullptr, 0, rs, c->rim_list[1], c->rim_n[1]);
+        if (rc) return rc;
+    }
     if (rs != c->stream) {   // whatever follows on the context's stream sees the rim's results
         HIPCHK(c, hipEventRecord(c->ev_f2_rim, rs));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
