@@ -309,11 +309,14 @@ def test_fused_equals_single_steps_256(lbm, preset_name, wide, monkeypatch):
     assert np.array_equal(fa, fb)
 
 
-def test_fused_equals_single_steps_car(lbm):
+def test_fused_equals_single_steps_car(lbm, monkeypatch):
     """BASELINE.json configs[2] at full size (512 x 256 x 256 wind tunnel + the voxelised car stand-in): 21 + 12 steps fused
     -- blocks running through the car, the rim's first step in the tail of the fused launch (rim 6 % of the cells), an
     even call ending on a pair -- against single steps"""
     import os
+    # the form of the first-step loads this domain settles on; left to the library it is still being timed over these
+    # few launches, and the rim keeps out of the fused launch while it is
+    monkeypatch.setenv("LBM_FUSED_WIDE", "0")
     car = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "car_like.obj")
     a = lbm.Solver(512, 256, 256, lbm.PRESET_WIND_TUNNEL, two_step=lbm.TWO_STEP_OFF)
     b = lbm.Solver(512, 256, 256, lbm.PRESET_WIND_TUNNEL)
