@@ -1102,6 +1102,12 @@ static int fused_pair(lbm_ctx* c, bool first) {
     // a side stream beside the fused kernel when the rim is more than 15 %.
     const bool tail = fused_tail_rim(c);
     const bool overlap = c->f2_overlap && !tail && c->rim_cells * 100 > cells(c) * c->f2_overlap_pct;
+    // (the rule can change between two pairs of a batch -- when the timing of the load forms ends -- so a pair that keeps
+    // to the context's stream still has to wait for a rim the previous one left on the side stream)
+    if (!overlap && c->f2_rim_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_f2_rim, 0));
+        c->f2_rim_pending = false;
+    }
     if (overlap) {
         if (!c->stream_rim) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream_rim, hipStreamNonBlocking));
