@@ -111,6 +111,26 @@ def test_where_the_rim_runs(oracle, lbm, preset, where, monkeypatch):
     fused_in_use(lbm, g)
 
 
+@pytest.mark.parametrize("preset", [0, 1])
+def test_rim_changes_place_inside_a_batch(oracle, lbm, preset):
+    """long batches on a small domain with obstacles: while the library times the two forms of the first-step loads (its
+    first 46 fused launches) the rim runs on the side stream, afterwards its first step rides in the fused launch -- the
+    switch happens between two pairs of ONE lbm_step() call and must not let a launch start before the rim of the pair
+    before it has ended"""
+    W, H, D = 136, 40, 36
+    o = oracle.Solver(W, H, D, preset)
+    g = lbm.Solver(W, H, D, preset)
+    for s in (o, g):
+        s.init()
+        s.add_solid(40, 0, 8, 20, 16, 14)
+        s.add_solid(W - 2, 18, 5, 2, 6, 9)
+    o.step(100); g.step(100)
+    same(o, g, f"preset {preset}, 100 steps")
+    o.step(31); g.step(31)
+    same(o, g, f"preset {preset}, 131 steps")
+    fused_in_use(lbm, g)
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("zsplit", [0, 1, 3])
 def test_fused_variants_with_obstacles(oracle, lbm, variant, zsplit, monkeypatch):
