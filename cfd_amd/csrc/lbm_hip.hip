@@ -1072,7 +1072,7 @@ static int launch_fused_timed(lbm_ctx* c, const float* in, float* out) {
     return LBM_OK;
 }
 
-// the rim's first step inside the fused launch (undecomposed contexts; F2Rim in k_fused2.h)
+// A step of the rim inside the fused launch (F2Rim in k_fused2.h): undecomposed contexts its first, z-slabs its second.
 // Pays where the launch has a ragged tail -- several rounds of blocks with the narrow first-step loads (obstacles, thin
 // slabs) -- or the rim is more than a few per cent of the cells.  With the wide loads every block issues the same requests
 // and all end within a microsecond of each other, in one round or in eight: such a launch only gets longer by the rim's
